@@ -1,0 +1,148 @@
+/*
+ * rsx.h -- C-ABI of the MI355X-native LSD radix sort (librsx.so).
+ *
+ * This is the drop-in boundary for the hot path of jgrodzki/radix_sort:
+ *     impl<T: RadixDigits> RadixSort<T> for [T] { fn radix_sort(&mut self) }
+ *         reference src/radix_sort/mod.rs:18-20,61-176
+ *     trait RadixDigits { const NUMBER_OF_DIGITS: u8; fn get_digit(&self, u8) -> u8 }
+ *         reference src/radix_sort/radix_digits.rs:1-5 (+ impls :7-136)
+ * The reference has no FFI layer of its own (pure Rust, bin crate); these are
+ * the entry points a Rust `extern "C"` block would bind so that the body of
+ * `radix_sort()` becomes one call (binding shown in INTEGRATION.md).
+ *
+ * Plain pointers and sizes only; no C++/torch types.  Every function returns
+ * an `int` status (0 = RSX_OK, negative = error) and never unwinds.
+ */
+#ifndef RSX_H
+#define RSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSX_VERSION 100 /* 0.1.0 */
+
+/* status codes */
+enum {
+    RSX_OK = 0,
+    RSX_ERR_ARG = -1,         /* bad pointer / size / layout */
+    RSX_ERR_UNSUPPORTED = -2, /* element size or key width without a device kernel */
+    RSX_ERR_HIP = -3,         /* a HIP runtime call failed; see rsx_last_error */
+    RSX_ERR_NOMEM = -4,       /* device workspace allocation failed */
+    RSX_ERR_NODEVICE = -5,    /* no gfx950-class device / wrong device */
+    RSX_ERR_WORKSPACE = -6,   /* workspace not reserved while growth is forbidden */
+    RSX_ERR_INTERNAL = -7     /* a bounded device-side wait gave up (protocol error); results invalid */
+};
+
+/* How a key is mapped to its order-preserving unsigned form before digits are
+ * taken; restates radix_digits.rs. */
+enum {
+    RSX_KEY_UNSIGNED = 0, /* u8,u16,u32,u64,u128,usize      radix_digits.rs:7-53   */
+    RSX_KEY_SIGNED = 1,   /* i8..i128,isize: x ^ MIN        radix_digits.rs:55-101 */
+    RSX_KEY_FLOAT = 2     /* f32,f64: b ^= (b>>31)|MIN      radix_digits.rs:103-124 */
+};
+
+/* Element descriptor: what `T: RadixDigits` means to the device.
+ *   elem_bytes  size_of::<T>()            (1,2,4,8,12,16,24,32 have kernels)
+ *   key_offset  byte offset of the key inside the element (0 for primitives;
+ *               offset_of!((K,U), 0) for tuples, radix_digits.rs:126-136)
+ *   key_bytes   1,2,4,8,16 == T::NUMBER_OF_DIGITS (8-bit digits, LSB first)
+ *   key_kind    RSX_KEY_*
+ * Elements are moved bitwise (mod.rs:133-140 uses copy_nonoverlapping), so any
+ * payload -- padding included -- is carried unchanged. */
+typedef struct rsx_layout {
+    uint32_t elem_bytes;
+    uint32_t key_offset;
+    uint32_t key_bytes;
+    uint32_t key_kind;
+} rsx_layout;
+
+typedef struct rsx_ctx rsx_ctx; /* owns device workspace; one in-flight call per ctx */
+
+/* -- context ------------------------------------------------------------- */
+/* Binds a context to HIP device `device` (-1 = current device). */
+int rsx_ctx_create(int device, rsx_ctx **out);
+int rsx_ctx_destroy(rsx_ctx *ctx);
+/* Pre-allocates the internal workspace for sorts of up to `n` elements of
+ * `layout` so that rsx_sort_device performs no allocation (stream-capture
+ * safe).  Replaces the reference's per-call temp-buffer allocation + page
+ * touch (mod.rs:71-82) for everything except the caller-owned ping-pong
+ * buffer. */
+int rsx_ctx_reserve(rsx_ctx *ctx, size_t n, const rsx_layout *layout);
+/* Synchronises `stream` and reports RSX_ERR_INTERNAL if any kernel of this
+ * context flagged a device-side protocol error since the last check (the
+ * reference panics on worker failure, mod.rs:106; across a C ABI that becomes
+ * a status).  rsx_sort_host calls it itself. */
+int rsx_ctx_check(rsx_ctx *ctx, void *stream);
+/* Last error text for this context (never NULL). */
+const char *rsx_last_error(const rsx_ctx *ctx);
+const char *rsx_strerror(int status);
+int rsx_version(void);
+
+/* -- the sort ------------------------------------------------------------ */
+/* In-place ascending stable sort of `n` elements resident in device memory:
+ * the device-side body of `<[T]>::radix_sort` (mod.rs:62-175).  `d_tmp` is the
+ * ping-pong buffer (the reference's `temp`, mod.rs:71-83), n*elem_bytes bytes,
+ * caller-owned.  All work is enqueued on `stream` (a hipStream_t, NULL =
+ * default stream); the call does not synchronise the device.  On return the
+ * result is (stream-ordered) in `d_data`, as after mod.rs:170-174. */
+int rsx_sort_device(rsx_ctx *ctx, void *d_data, void *d_tmp, size_t n, const rsx_layout *layout,
+                    void *stream);
+
+/* Literal drop-in for `&mut [T]` in host memory: H2D, rsx_sort_device, D2H,
+ * blocking (mod.rs:62 is blocking too).  PCIe-bound; not the measured path. */
+int rsx_sort_host(rsx_ctx *ctx, void *data, size_t n, const rsx_layout *layout);
+
+/* -- per-pass building blocks (multi-GPU bucket exchange) ---------------- */
+/* 256-bin count of digit `digit` (0 = least significant) over `n` elements:
+ * the count phase, mod.rs:90-109, with "chunk" = this device's slice.
+ * `d_hist` receives 256 uint64 counts (overwritten). */
+int rsx_histogram_device(rsx_ctx *ctx, const void *d_src, size_t n, const rsx_layout *layout,
+                         uint32_t digit, uint64_t *d_hist, void *stream);
+/* One stable LSD pass by `digit`, d_src -> d_dst (count -> scan -> scatter of
+ * mod.rs:90-168 for one current_digit_index).  If `d_hist` is non-NULL it
+ * receives the 256 uint64 digit counts of the slice. */
+int rsx_partition_device(rsx_ctx *ctx, const void *d_src, void *d_dst, size_t n,
+                         const rsx_layout *layout, uint32_t digit, uint64_t *d_hist, void *stream);
+/* Segmented device copy: for i in [0, nseg): copy len[i] ELEMENTS of
+ * `elem_bytes` from d_src + src_off[i] to d_dst + dst_off[i] (offsets in
+ * elements).  Places the received (digit, source-GPU) runs after the
+ * all-to-all -- the "digit-major, chunk-minor" order of mod.rs:110-120 with
+ * chunk == GPU.  The three tables are device arrays of nseg uint64. */
+int rsx_segmented_copy_device(rsx_ctx *ctx, const void *d_src, void *d_dst, uint32_t elem_bytes,
+                              const uint64_t *d_src_off, const uint64_t *d_dst_off,
+                              const uint64_t *d_len, uint32_t nseg, void *stream);
+
+/* -- harness helpers (input generation / verification on device) --------- */
+enum {
+    RSX_GEN_UNIFORM = 0, /* key = splitmix64(seed, i) truncated        (distr.rs:40-52 KeyUniform shape) */
+    RSX_GEN_ZIPF = 1,    /* key ~ Zipf(N = 2^bits - 1, s = param)      (distr.rs:54-76,108-130)         */
+    RSX_GEN_STEP = 2,    /* key uniform over `param` equally spaced values (distr.rs:78-106,132-160)    */
+    RSX_GEN_SORTED = 3,  /* key = i (already sorted)                                                   */
+    RSX_GEN_REVERSED = 4,/* key = n-1-i                                                                */
+    RSX_GEN_CONSTANT = 5 /* key = param                                                                */
+};
+/* Fills `n` elements: key field generated as above (counter-based, so the
+ * same (seed, index) gives the same key on any device or on the host), every
+ * payload byte outside the key holds the low bytes of the element's global
+ * index `index_base + i` (reveals instability; the reference uses payload 0,
+ * distr.rs:22-26). */
+int rsx_generate_device(rsx_ctx *ctx, void *d_data, size_t n, const rsx_layout *layout, int gen,
+                        uint64_t seed, double param, uint64_t index_base, void *stream);
+/* Order check + order-independent checksum, on device:
+ *   out[0] = number of adjacent pairs (i, i+1) with mapped_key[i] > mapped_key[i+1]
+ *   out[1] = sum over elements of hash(element bytes) mod 2^64 (multiset checksum)
+ *   out[2] = number of adjacent equal-key pairs whose payload index decreases
+ *            (stability violations; meaningful for rsx_generate_device payloads,
+ *            elements with payload bytes only)
+ * `d_out` is 3 uint64 on the device (overwritten). */
+int rsx_verify_device(rsx_ctx *ctx, const void *d_data, size_t n, const rsx_layout *layout,
+                      uint64_t *d_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSX_H */

@@ -1,0 +1,266 @@
+/*
+ * rsx_oracle.c -- CPU restatement of jgrodzki/radix_sort's LSD radix sort.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under radix_sort_amd/ (the product) may
+ * include, link, import or execute this file; only tests/, bench.py's
+ * `cpu_baseline` leg and __graft_entry__.smoke() use it, and only as the
+ * checker / the timed CPU baseline, never as the thing shipped.
+ *
+ * What it restates (file:line relative to the reference checkout):
+ *   - key -> digit maps ............ src/radix_sort/radix_digits.rs:7-136
+ *   - single-thread LSD ............ src/radix_sort/mod.rs:183-212 (radix_sort0)
+ *   - thread-parallel LSD .......... src/radix_sort/mod.rs:61-176  (radix_sort)
+ *       chunking                     mod.rs:66-70
+ *       temp alloc + page touch      mod.rs:71-82
+ *       ping-pong                    mod.rs:84-89
+ *       count                        mod.rs:90-109
+ *       digit-major/chunk-minor scan mod.rs:110-120
+ *       96-element buffered scatter  mod.rs:121-168
+ *       odd-D copy-back              mod.rs:170-174
+ *
+ * Pinning: the reference ships NO golden vectors (tests.rs draws from an
+ * unseeded thread_rng); what its tests pin is a property with a unique answer
+ * -- output == stable sort by mapped key (tests.rs:7-23,133-187).  This oracle
+ * is checked against that property through an independent implementation
+ * (numpy stable argsort on the mapped key) in tests/test_oracle.py, and the
+ * fixtures in tests/golden/ are produced by both and required to agree.
+ *
+ * Elements are opaque byte strings of `elem_bytes`; the key is the
+ * little-endian integer of `key_bytes` at `key_offset` (Rust primitives on the
+ * x86-64/little-endian targets the reference runs on; tuples `(T,U)` have the
+ * key `.0` at a run-time offset -- radix_digits.rs:126-136).
+ */
+#define _GNU_SOURCE
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+enum { ORC_UNSIGNED = 0, ORC_SIGNED = 1, ORC_FLOAT = 2 };
+
+typedef struct {
+    uint32_t elem_bytes;
+    uint32_t key_offset;
+    uint32_t key_bytes; /* 1,2,4,8,16 == NUMBER_OF_DIGITS */
+    uint32_t key_kind;
+} orc_layout;
+
+/* radix_digits.rs: get_digit(index).
+ *   unsigned (7-53):  (x >> 8*index) as u8                -> byte `index`
+ *   signed  (55-101): ((x ^ MIN) >> 8*index) as u8        -> top byte ^ 0x80
+ *   float  (103-124): b ^= (b >> (bits-1)) | MIN; byte    -> negative: every
+ *                     byte ^ 0xFF, non-negative: top byte ^ 0x80
+ */
+static inline uint32_t orc_digit(const uint8_t *e, const orc_layout *L, uint32_t index) {
+    const uint8_t *k = e + L->key_offset;
+    uint32_t top = L->key_bytes - 1;
+    uint8_t b = k[index];
+    switch (L->key_kind) {
+    case ORC_SIGNED:
+        if (index == top) b ^= 0x80;
+        break;
+    case ORC_FLOAT:
+        if (k[top] & 0x80) b ^= 0xFF;
+        else if (index == top) b ^= 0x80;
+        break;
+    default:
+        break;
+    }
+    return b;
+}
+
+uint32_t orc_get_digit(const void *elem, const orc_layout *L, uint32_t index) {
+    return orc_digit((const uint8_t *)elem, L, index);
+}
+
+/* mapped key of one element as `key_bytes` little-endian bytes (order-preserving
+ * as an unsigned integer) -- used by the numpy cross-check. */
+void orc_map_keys(const void *data, size_t n, const orc_layout *L, void *out) {
+    const uint8_t *p = (const uint8_t *)data;
+    uint8_t *o = (uint8_t *)out;
+    for (size_t i = 0; i < n; ++i)
+        for (uint32_t d = 0; d < L->key_bytes; ++d)
+            o[i * L->key_bytes + d] = (uint8_t)orc_digit(p + i * L->elem_bytes, L, d);
+}
+
+/* ---- mod.rs:183-212  radix_sort0: single thread ------------------------- */
+int orc_radix_sort0(void *data, size_t n, const orc_layout *L) {
+    const size_t s = L->elem_bytes;
+    if (n == 0) return 0;
+    uint8_t *self = (uint8_t *)data;
+    uint8_t *temp = (uint8_t *)malloc(n * s); /* vec![T::default(); len] */
+    if (!temp) return -1;
+    for (uint32_t d = 0; d < L->key_bytes; ++d) {
+        const uint8_t *src = (d % 2 == 0) ? self : temp; /* mod.rs:186-190 */
+        uint8_t *dst = (d % 2 == 0) ? temp : self;
+        size_t hist[256] = {0};
+        for (size_t i = 0; i < n; ++i) hist[orc_digit(src + i * s, L, d)]++; /* :192-194 */
+        size_t start = 0; /* fold exclusive scan :195-202 */
+        for (int v = 0; v < 256; ++v) {
+            size_t c = hist[v];
+            hist[v] = start;
+            start += c;
+        }
+        for (size_t i = 0; i < n; ++i) { /* :203-207 */
+            uint32_t v = orc_digit(src + i * s, L, d);
+            memcpy(dst + hist[v] * s, src + i * s, s);
+            hist[v]++;
+        }
+    }
+    if (L->key_bytes % 2 == 1) memcpy(self, temp, n * s); /* :209-211 */
+    free(temp);
+    return 0;
+}
+
+/* ---- mod.rs:61-176  radix_sort: thread-parallel -------------------------- */
+#define ORC_BUFFER_SIZE 96 /* mod.rs:64 */
+#define ORC_PAGE_SIZE 4096 /* mod.rs:65 */
+
+typedef struct {
+    const uint8_t *src;
+    uint8_t *dst;
+    size_t begin, end; /* element range of this chunk */
+    const orc_layout *L;
+    uint32_t digit;
+    size_t hist[256]; /* count out / bin_starts in */
+    uint8_t *derand;  /* 256 * 96 * s bytes, thread-private (mod.rs:126-129) */
+} orc_job;
+
+static void *orc_count_worker(void *arg) { /* mod.rs:94-100 */
+    orc_job *j = (orc_job *)arg;
+    const size_t s = j->L->elem_bytes;
+    memset(j->hist, 0, sizeof j->hist);
+    for (size_t i = j->begin; i < j->end; ++i) j->hist[orc_digit(j->src + i * s, j->L, j->digit)]++;
+    return NULL;
+}
+
+static void *orc_scatter_worker(void *arg) { /* mod.rs:125-166 */
+    orc_job *j = (orc_job *)arg;
+    const size_t s = j->L->elem_bytes;
+    size_t sizes[256] = {0};
+    for (size_t i = j->begin; i < j->end; ++i) {
+        const uint8_t *e = j->src + i * s;
+        uint32_t v = orc_digit(e, j->L, j->digit);
+        memcpy(j->derand + ((size_t)v * ORC_BUFFER_SIZE + sizes[v]) * s, e, s); /* :133-141 */
+        if (++sizes[v] == ORC_BUFFER_SIZE) {                                     /* :142-153 */
+            memcpy(j->dst + j->hist[v] * s, j->derand + (size_t)v * ORC_BUFFER_SIZE * s,
+                   ORC_BUFFER_SIZE * s);
+            j->hist[v] += ORC_BUFFER_SIZE;
+            sizes[v] = 0;
+        }
+    }
+    for (int v = 0; v < 256; ++v) /* :155-165 */
+        if (sizes[v] > 0)
+            memcpy(j->dst + j->hist[v] * s, j->derand + (size_t)v * ORC_BUFFER_SIZE * s, sizes[v] * s);
+    return NULL;
+}
+
+/* `threads` plays available_parallelism() (mod.rs:66-70).  The reference panics
+ * on an empty slice (chunks(0)); there is no output to compare, so n == 0 is a
+ * no-op here.  Returns 0, or -1 on allocation/thread failure. */
+int orc_radix_sort(void *data, size_t n, const orc_layout *L, int threads) {
+    const size_t s = L->elem_bytes;
+    if (n == 0) return 0;
+    if (threads < 1) threads = 1;
+    const size_t per = (n + (size_t)threads - 1) / (size_t)threads; /* div_ceil :66-70 */
+    const size_t chunks = (n + per - 1) / per;                      /* src.chunks(per) */
+    uint8_t *self = (uint8_t *)data;
+    uint8_t *temp = (uint8_t *)malloc(n * s); /* uninitialised, :71-73 */
+    orc_job *jobs = (orc_job *)calloc(chunks, sizeof(orc_job));
+    pthread_t *tids = (pthread_t *)calloc(chunks, sizeof(pthread_t));
+    uint8_t *derand = (uint8_t *)malloc(chunks * 256 * ORC_BUFFER_SIZE * s);
+    int rc = 0;
+    if (!temp || !jobs || !tids || !derand) {
+        rc = -1;
+        goto out;
+    }
+    for (size_t b = 0; b < n * s; b += ORC_PAGE_SIZE) temp[b] = 0; /* page touch :74-82 */
+    for (size_t c = 0; c < chunks; ++c) {
+        jobs[c].begin = c * per;
+        jobs[c].end = (c + 1) * per < n ? (c + 1) * per : n;
+        jobs[c].L = L;
+        jobs[c].derand = derand + c * 256 * ORC_BUFFER_SIZE * s;
+    }
+    for (uint32_t d = 0; d < L->key_bytes; ++d) { /* :84 */
+        const uint8_t *src = (d % 2 == 0) ? self : temp; /* :85-89 */
+        uint8_t *dst = (d % 2 == 0) ? temp : self;
+        for (size_t c = 0; c < chunks; ++c) {
+            jobs[c].src = src;
+            jobs[c].dst = dst;
+            jobs[c].digit = d;
+        }
+        /* count: one OS thread per chunk, spawned per pass (:90-109) */
+        if (chunks == 1) orc_count_worker(&jobs[0]);
+        else {
+            for (size_t c = 0; c < chunks; ++c)
+                if (pthread_create(&tids[c], NULL, orc_count_worker, &jobs[c])) {
+                    for (size_t k = 0; k < c; ++k) pthread_join(tids[k], NULL);
+                    rc = -1;
+                    goto out;
+                }
+            for (size_t c = 0; c < chunks; ++c) pthread_join(tids[c], NULL);
+        }
+        /* prefix: digit-major, chunk-minor exclusive running sum (:110-120) */
+        size_t prefix = 0;
+        for (int v = 0; v < 256; ++v)
+            for (size_t c = 0; c < chunks; ++c) {
+                size_t cnt = jobs[c].hist[v];
+                jobs[c].hist[v] = prefix;
+                prefix += cnt;
+            }
+        /* scatter through 96-element write-combining buffers (:121-168) */
+        if (chunks == 1) orc_scatter_worker(&jobs[0]);
+        else {
+            for (size_t c = 0; c < chunks; ++c)
+                if (pthread_create(&tids[c], NULL, orc_scatter_worker, &jobs[c])) {
+                    for (size_t k = 0; k < c; ++k) pthread_join(tids[k], NULL);
+                    rc = -1;
+                    goto out;
+                }
+            for (size_t c = 0; c < chunks; ++c) pthread_join(tids[c], NULL);
+        }
+    }
+    if (L->key_bytes % 2 == 1) memcpy(self, temp, n * s); /* :170-174 */
+out:
+    free(derand);
+    free(tids);
+    free(jobs);
+    free(temp);
+    return rc;
+}
+
+/* One LSD pass (count -> scan -> scatter of digit `d`) src -> dst, single
+ * thread: the unit the multi-GPU driver's per-pass bucket exchange is checked
+ * against (mod.rs:191-207 for one value of current_digit_index). */
+int orc_partition_pass(const void *src_, void *dst_, size_t n, const orc_layout *L, uint32_t d,
+                       uint64_t *hist_out /* [256] counts, may be NULL */) {
+    const size_t s = L->elem_bytes;
+    const uint8_t *src = (const uint8_t *)src_;
+    uint8_t *dst = (uint8_t *)dst_;
+    size_t hist[256] = {0};
+    for (size_t i = 0; i < n; ++i) hist[orc_digit(src + i * s, L, d)]++;
+    size_t start = 0;
+    for (int v = 0; v < 256; ++v) {
+        size_t c = hist[v];
+        if (hist_out) hist_out[v] = c;
+        hist[v] = start;
+        start += c;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t v = orc_digit(src + i * s, L, d);
+        memcpy(dst + hist[v] * s, src + i * s, s);
+        hist[v]++;
+    }
+    return 0;
+}
+
+/* Counter-based input generator shared with the GPU side (SplitMix64 of
+ * seed + index): lets CPU and GPU build identical arrays without PCIe.
+ * Harness-side only (replaces thread_rng of main.rs:27-30 / tests.rs). */
+static inline uint64_t orc_splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+uint64_t orc_rand64(uint64_t seed, uint64_t index) { return orc_splitmix64(seed + index * 0x9E3779B97F4A7C15ull); }

@@ -1,0 +1,486 @@
+// rsx.hip -- host side of librsx.so: the C-ABI of include/rsx.h over the gfx950
+// kernels in rsx_device.hpp.  Plays the role of the body of
+// `<[T]>::radix_sort` (reference src/radix_sort/mod.rs:62-175): pass loop,
+// ping-pong, odd-D copy-back -- with every phase a stream-ordered launch.
+#include "rsx_device.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+
+#include "../../include/rsx.h"
+
+using namespace rsx;
+
+struct rsx_ctx {
+    int device = 0;
+    std::mutex mu;
+    std::string err = "";
+    // block zeroed before every pass: [ticket (16 B)][status words]
+    void* zero_blk = nullptr;
+    size_t zero_bytes = 0;
+    // aux: [ghist 16*256 u64][counts 16*256 u64][error u32 + pad]
+    void* aux = nullptr;
+    // staging for rsx_sort_host
+    void* host_buf[2] = {nullptr, nullptr};
+    size_t host_bytes = 0;
+    int num_cu = 256;
+};
+
+namespace {
+
+constexpr size_t GHIST_BYTES = 16 * RADIX * sizeof(uint64_t);
+constexpr size_t AUX_BYTES = 2 * GHIST_BYTES + 64;
+constexpr int SWEEP_WG = 512;
+
+int fail(rsx_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
+    if (c) {
+        c->err = what;
+        if (e != hipSuccess) {
+            c->err += ": ";
+            c->err += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+#define RSX_HIP(call)                                                   \
+    do {                                                                \
+        hipError_t _e = (call);                                         \
+        if (_e != hipSuccess) return fail(ctx, RSX_ERR_HIP, #call, _e); \
+    } while (0)
+
+bool layout_ok(const rsx_layout* L) {
+    if (!L) return false;
+    const uint32_t kb = L->key_bytes;
+    if (!(kb == 1 || kb == 2 || kb == 4 || kb == 8 || kb == 16)) return false;
+    if (L->key_kind > RSX_KEY_FLOAT) return false;
+    if (L->key_kind == RSX_KEY_FLOAT && !(kb == 4 || kb == 8)) return false;
+    if (L->elem_bytes == 0 || (uint64_t)L->key_offset + kb > L->elem_bytes) return false;
+    return true;
+}
+bool size_supported(uint32_t es) {
+    return es == 1 || es == 2 || es == 4 || es == 8 || es == 12 || es == 16 || es == 24 || es == 32;
+}
+uint32_t elem_align(uint32_t es) {
+    switch (es) {
+        case 1: return 1;
+        case 2: return 2;
+        case 4: case 12: return 4;
+        case 8: case 24: return 8;
+        default: return 16;
+    }
+}
+bool aligned(const void* p, uint32_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+// keys per thread by element size: keeps the LDS tile at 32 KiB (ES >= 4)
+constexpr int kpt_for(int es) {
+    return es <= 4 ? 16 : es == 8 ? 8 : es == 12 ? 5 : es == 16 ? 4 : es == 24 ? 3 : 2;
+}
+uint32_t tile_elems(uint32_t es) { return SWEEP_WG * kpt_for((int)es); }
+
+DigitSpec make_spec(const rsx_layout* L, uint32_t digit) {
+    DigitSpec s;
+    s.byte = L->key_offset + digit;
+    s.top_byte = L->key_offset + L->key_bytes - 1;
+    s.flip = (L->key_kind != RSX_KEY_UNSIGNED && digit == L->key_bytes - 1) ? 0x80u : 0u;
+    s.is_float = L->key_kind == RSX_KEY_FLOAT;
+    return s;
+}
+
+uint64_t* ghist_of(rsx_ctx* c) { return static_cast<uint64_t*>(c->aux); }
+uint64_t* counts_of(rsx_ctx* c) { return reinterpret_cast<uint64_t*>(static_cast<char*>(c->aux) + GHIST_BYTES); }
+uint32_t* error_of(rsx_ctx* c) { return reinterpret_cast<uint32_t*>(static_cast<char*>(c->aux) + 2 * GHIST_BYTES); }
+
+size_t zero_bytes_for(size_t n, uint32_t es) {
+    const uint64_t tile = tile_elems(es);
+    const uint64_t ntiles = (n + tile - 1) / tile;
+    const size_t sw = n <= (1ull << 30) ? 4 : 8;
+    return 16 + (size_t)ntiles * RADIX * sw;
+}
+
+int ensure_workspace(rsx_ctx* ctx, size_t n, const rsx_layout* L) {
+    if (!ctx->aux) {
+        RSX_HIP(hipMalloc(&ctx->aux, AUX_BYTES));
+        RSX_HIP(hipMemset(ctx->aux, 0, AUX_BYTES));
+    }
+    const size_t need = zero_bytes_for(n, L->elem_bytes);
+    if (need > ctx->zero_bytes) {
+        if (ctx->zero_blk) RSX_HIP(hipFree(ctx->zero_blk));
+        ctx->zero_blk = nullptr;
+        ctx->zero_bytes = 0;
+        hipError_t e = hipMalloc(&ctx->zero_blk, need);
+        if (e != hipSuccess) return fail(ctx, RSX_ERR_NOMEM, "workspace hipMalloc", e);
+        ctx->zero_bytes = need;
+    }
+    return RSX_OK;
+}
+
+template <int ES>
+int launch_hist(rsx_ctx* ctx, const void* src, size_t n, const rsx_layout* L, uint32_t d0, uint32_t nd,
+                uint64_t* ghist, hipStream_t st) {
+    const uint64_t per_block = 512ull * 16;
+    uint64_t blocks = (n + per_block - 1) / per_block;
+    const uint64_t cap = (uint64_t)ctx->num_cu * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL((rsx_hist_kernel<ES>), dim3((uint32_t)blocks), dim3(512), nd * RADIX * sizeof(uint32_t), st,
+                       static_cast<const Elem<ES>*>(src), (uint64_t)n, ghist, L->key_offset, L->key_bytes,
+                       L->key_kind, d0, nd);
+    RSX_HIP(hipGetLastError());
+    return RSX_OK;
+}
+
+template <int ES, typename S>
+int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, size_t n, const rsx_layout* L, uint32_t digit,
+                   const uint64_t* digit_start, hipStream_t st) {
+    constexpr int KPT = kpt_for(ES);
+    constexpr int TILE = SWEEP_WG * KPT;
+    const uint64_t ntiles = (n + TILE - 1) / TILE;
+    const size_t zb = 16 + (size_t)ntiles * RADIX * sizeof(S);
+    RSX_HIP(hipMemsetAsync(ctx->zero_blk, 0, zb, st));
+    SweepArgs a;
+    a.src = src;
+    a.dst = dst;
+    a.n = n;
+    a.digit_start = digit_start;
+    a.ticket = static_cast<uint32_t*>(ctx->zero_blk);
+    a.status = static_cast<char*>(ctx->zero_blk) + 16;
+    a.error = error_of(ctx);
+    a.spec = make_spec(L, digit);
+    const size_t lds = (size_t)TILE * ES + RADIX * sizeof(uint64_t) + (SWEEP_WG / WAVE) * RADIX * sizeof(uint32_t) + 32;
+    hipLaunchKernelGGL((rsx_onesweep_kernel<ES, KPT, SWEEP_WG, S>), dim3((uint32_t)ntiles), dim3(SWEEP_WG), lds, st,
+                       a);
+    RSX_HIP(hipGetLastError());
+    return RSX_OK;
+}
+
+template <int ES>
+int launch_sweep(rsx_ctx* ctx, const void* src, void* dst, size_t n, const rsx_layout* L, uint32_t digit,
+                 const uint64_t* digit_start, hipStream_t st) {
+    if (n <= (1ull << 30)) return launch_sweep_t<ES, uint32_t>(ctx, src, dst, n, L, digit, digit_start, st);
+    return launch_sweep_t<ES, uint64_t>(ctx, src, dst, n, L, digit, digit_start, st);
+}
+
+#define RSX_DISPATCH_ES(es, FN, ...)                           \
+    switch (es) {                                              \
+        case 1: return FN<1>(__VA_ARGS__);                     \
+        case 2: return FN<2>(__VA_ARGS__);                     \
+        case 4: return FN<4>(__VA_ARGS__);                     \
+        case 8: return FN<8>(__VA_ARGS__);                     \
+        case 12: return FN<12>(__VA_ARGS__);                   \
+        case 16: return FN<16>(__VA_ARGS__);                   \
+        case 24: return FN<24>(__VA_ARGS__);                   \
+        case 32: return FN<32>(__VA_ARGS__);                   \
+        default: return fail(ctx, RSX_ERR_UNSUPPORTED, "element size has no device kernel"); \
+    }
+
+int hist_dispatch(rsx_ctx* ctx, const void* src, size_t n, const rsx_layout* L, uint32_t d0, uint32_t nd,
+                  uint64_t* ghist, hipStream_t st) {
+    RSX_DISPATCH_ES(L->elem_bytes, launch_hist, ctx, src, n, L, d0, nd, ghist, st)
+}
+int sweep_dispatch(rsx_ctx* ctx, const void* src, void* dst, size_t n, const rsx_layout* L, uint32_t digit,
+                   const uint64_t* digit_start, hipStream_t st) {
+    RSX_DISPATCH_ES(L->elem_bytes, launch_sweep, ctx, src, dst, n, L, digit, digit_start, st)
+}
+
+template <int ES>
+int launch_segcopy(rsx_ctx* ctx, const void* src, void* dst, const uint64_t* so, const uint64_t* dof,
+                   const uint64_t* len, uint32_t nseg, hipStream_t st) {
+    const uint32_t bps = 8;
+    hipLaunchKernelGGL((rsx_segcopy_kernel<ES>), dim3(nseg * bps), dim3(256), 0, st,
+                       static_cast<const Elem<ES>*>(src), static_cast<Elem<ES>*>(dst), so, dof, len, nseg, bps);
+    RSX_HIP(hipGetLastError());
+    return RSX_OK;
+}
+
+int check_common(rsx_ctx* ctx, const rsx_layout* L) {
+    if (!ctx) return RSX_ERR_ARG;
+    if (!layout_ok(L)) return fail(ctx, RSX_ERR_ARG, "invalid rsx_layout");
+    if (!size_supported(L->elem_bytes)) return fail(ctx, RSX_ERR_UNSUPPORTED, "element size has no device kernel");
+    return RSX_OK;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int rsx_version(void) { return RSX_VERSION; }
+
+const char* rsx_strerror(int status) {
+    switch (status) {
+        case RSX_OK: return "ok";
+        case RSX_ERR_ARG: return "invalid argument";
+        case RSX_ERR_UNSUPPORTED: return "unsupported element layout";
+        case RSX_ERR_HIP: return "HIP runtime error";
+        case RSX_ERR_NOMEM: return "out of device memory";
+        case RSX_ERR_NODEVICE: return "no usable device";
+        case RSX_ERR_WORKSPACE: return "workspace not reserved";
+        case RSX_ERR_INTERNAL: return "device-side protocol error";
+        default: return "unknown status";
+    }
+}
+
+const char* rsx_last_error(const rsx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int rsx_ctx_create(int device, rsx_ctx** out) try {
+    if (!out) return RSX_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return RSX_ERR_NODEVICE;
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) return RSX_ERR_NODEVICE;
+    }
+    if (device >= count) return RSX_ERR_NODEVICE;
+    rsx_ctx* ctx = new (std::nothrow) rsx_ctx();
+    if (!ctx) return RSX_ERR_NOMEM;
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {  // code objects are gfx950-only
+            delete ctx;
+            return RSX_ERR_NODEVICE;
+        }
+    }
+    *out = ctx;
+    return RSX_OK;
+} catch (...) {
+    return RSX_ERR_NOMEM;
+}
+
+int rsx_ctx_destroy(rsx_ctx* ctx) try {
+    if (!ctx) return RSX_ERR_ARG;
+    {
+        DeviceGuard g(ctx->device);
+        if (ctx->zero_blk) (void)hipFree(ctx->zero_blk);
+        if (ctx->aux) (void)hipFree(ctx->aux);
+        for (void* p : ctx->host_buf)
+            if (p) (void)hipFree(p);
+    }
+    delete ctx;
+    return RSX_OK;
+} catch (...) {
+    return RSX_ERR_HIP;
+}
+
+int rsx_ctx_reserve(rsx_ctx* ctx, size_t n, const rsx_layout* layout) try {
+    int rc = check_common(ctx, layout);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    return ensure_workspace(ctx, n, layout);
+} catch (...) {
+    return RSX_ERR_NOMEM;
+}
+
+int rsx_ctx_check(rsx_ctx* ctx, void* stream) try {
+    if (!ctx) return RSX_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    RSX_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    if (!ctx->aux) return RSX_OK;
+    uint32_t e = 0;
+    RSX_HIP(hipMemcpy(&e, error_of(ctx), sizeof e, hipMemcpyDeviceToHost));
+    if (e) {
+        (void)hipMemset(error_of(ctx), 0, sizeof e);
+        return fail(ctx, RSX_ERR_INTERNAL, "look-back spin gave up (device protocol error)");
+    }
+    return RSX_OK;
+} catch (...) {
+    return RSX_ERR_HIP;
+}
+
+int rsx_sort_device(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const rsx_layout* L, void* stream) try {
+    int rc = check_common(ctx, L);
+    if (rc) return rc;
+    if (n <= 1) return RSX_OK;  // reference panics on n == 0 (mod.rs:66-70,92); nothing to compare
+    if (!d_data || !d_tmp) return fail(ctx, RSX_ERR_ARG, "null device pointer");
+    const uint32_t al = elem_align(L->elem_bytes);
+    if (!aligned(d_data, al) || !aligned(d_tmp, al)) return fail(ctx, RSX_ERR_ARG, "device pointer misaligned");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return fail(ctx, RSX_ERR_NODEVICE, "hipSetDevice failed");
+    rc = ensure_workspace(ctx, n, L);
+    if (rc) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint32_t D = L->key_bytes;  // T::NUMBER_OF_DIGITS
+    uint64_t* ghist = ghist_of(ctx);
+    // count (all digits, one read) + per-digit exclusive scan
+    RSX_HIP(hipMemsetAsync(ghist, 0, (size_t)D * RADIX * sizeof(uint64_t), st));
+    rc = hist_dispatch(ctx, d_data, n, L, 0, D, ghist, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(rsx_scan_kernel, dim3(D), dim3(RADIX), 0, st, ghist, (uint64_t*)nullptr);
+    RSX_HIP(hipGetLastError());
+    // pass loop with ping-pong (mod.rs:84-89)
+    for (uint32_t d = 0; d < D; ++d) {
+        const void* src = (d % 2 == 0) ? d_data : d_tmp;
+        void* dst = (d % 2 == 0) ? d_tmp : d_data;
+        rc = sweep_dispatch(ctx, src, dst, n, L, d, ghist + (size_t)d * RADIX, st);
+        if (rc) return rc;
+    }
+    if (D % 2 == 1)  // odd-D copy-back (mod.rs:170-174)
+        RSX_HIP(hipMemcpyAsync(d_data, d_tmp, n * (size_t)L->elem_bytes, hipMemcpyDeviceToDevice, st));
+    return RSX_OK;
+} catch (...) {
+    return RSX_ERR_HIP;
+}
+
+int rsx_sort_host(rsx_ctx* ctx, void* data, size_t n, const rsx_layout* L) try {
+    int rc = check_common(ctx, L);
+    if (rc) return rc;
+    if (n <= 1) return RSX_OK;
+    if (!data) return fail(ctx, RSX_ERR_ARG, "null host pointer");
+    const size_t bytes = n * (size_t)L->elem_bytes;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        DeviceGuard g(ctx->device);
+        if (bytes > ctx->host_bytes) {
+            for (void*& p : ctx->host_buf) {
+                if (p) (void)hipFree(p);
+                p = nullptr;
+            }
+            ctx->host_bytes = 0;
+            for (void*& p : ctx->host_buf) {
+                hipError_t e = hipMalloc(&p, bytes);
+                if (e != hipSuccess) return fail(ctx, RSX_ERR_NOMEM, "staging hipMalloc", e);
+            }
+            ctx->host_bytes = bytes;
+        }
+        RSX_HIP(hipMemcpy(ctx->host_buf[0], data, bytes, hipMemcpyHostToDevice));
+    }
+    rc = rsx_sort_device(ctx, ctx->host_buf[0], ctx->host_buf[1], n, L, nullptr);
+    if (rc) return rc;
+    rc = rsx_ctx_check(ctx, nullptr);
+    if (rc) return rc;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        DeviceGuard g(ctx->device);
+        RSX_HIP(hipMemcpy(data, ctx->host_buf[0], bytes, hipMemcpyDeviceToHost));
+    }
+    return RSX_OK;
+} catch (...) {
+    return RSX_ERR_HIP;
+}
+
+int rsx_histogram_device(rsx_ctx* ctx, const void* d_src, size_t n, const rsx_layout* L, uint32_t digit,
+                         uint64_t* d_hist, void* stream) try {
+    int rc = check_common(ctx, L);
+    if (rc) return rc;
+    if (digit >= L->key_bytes || !d_hist) return fail(ctx, RSX_ERR_ARG, "bad digit / null histogram");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    RSX_HIP(hipMemsetAsync(d_hist, 0, RADIX * sizeof(uint64_t), st));
+    if (n == 0) return RSX_OK;
+    if (!d_src || !aligned(d_src, elem_align(L->elem_bytes))) return fail(ctx, RSX_ERR_ARG, "bad source pointer");
+    return hist_dispatch(ctx, d_src, n, L, digit, 1, d_hist, st);
+} catch (...) {
+    return RSX_ERR_HIP;
+}
+
+int rsx_partition_device(rsx_ctx* ctx, const void* d_src, void* d_dst, size_t n, const rsx_layout* L,
+                         uint32_t digit, uint64_t* d_hist, void* stream) try {
+    int rc = check_common(ctx, L);
+    if (rc) return rc;
+    if (digit >= L->key_bytes) return fail(ctx, RSX_ERR_ARG, "bad digit");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (n == 0) {
+        if (d_hist) RSX_HIP(hipMemsetAsync(d_hist, 0, RADIX * sizeof(uint64_t), st));
+        return RSX_OK;
+    }
+    const uint32_t al = elem_align(L->elem_bytes);
+    if (!d_src || !d_dst || !aligned(d_src, al) || !aligned(d_dst, al))
+        return fail(ctx, RSX_ERR_ARG, "bad device pointer");
+    rc = ensure_workspace(ctx, n, L);
+    if (rc) return rc;
+    uint64_t* ghist = ghist_of(ctx);
+    RSX_HIP(hipMemsetAsync(ghist, 0, RADIX * sizeof(uint64_t), st));
+    rc = hist_dispatch(ctx, d_src, n, L, digit, 1, ghist, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(rsx_scan_kernel, dim3(1), dim3(RADIX), 0, st, ghist, d_hist);
+    RSX_HIP(hipGetLastError());
+    return sweep_dispatch(ctx, d_src, d_dst, n, L, digit, ghist, st);
+} catch (...) {
+    return RSX_ERR_HIP;
+}
+
+int rsx_segmented_copy_device(rsx_ctx* ctx, const void* d_src, void* d_dst, uint32_t elem_bytes,
+                              const uint64_t* d_src_off, const uint64_t* d_dst_off, const uint64_t* d_len,
+                              uint32_t nseg, void* stream) try {
+    if (!ctx) return RSX_ERR_ARG;
+    if (nseg == 0) return RSX_OK;
+    if (!d_src || !d_dst || !d_src_off || !d_dst_off || !d_len) return fail(ctx, RSX_ERR_ARG, "null pointer");
+    if (!size_supported(elem_bytes)) return fail(ctx, RSX_ERR_UNSUPPORTED, "element size has no device kernel");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    RSX_DISPATCH_ES(elem_bytes, launch_segcopy, ctx, d_src, d_dst, d_src_off, d_dst_off, d_len, nseg, st)
+} catch (...) {
+    return RSX_ERR_HIP;
+}
+
+int rsx_generate_device(rsx_ctx* ctx, void* d_data, size_t n, const rsx_layout* L, int gen, uint64_t seed,
+                        double param, uint64_t index_base, void* stream) try {
+    if (!ctx) return RSX_ERR_ARG;
+    if (!layout_ok(L)) return fail(ctx, RSX_ERR_ARG, "invalid rsx_layout");
+    if (n == 0) return RSX_OK;
+    if (!d_data) return fail(ctx, RSX_ERR_ARG, "null pointer");
+    if (gen < RSX_GEN_UNIFORM || gen > RSX_GEN_CONSTANT) return fail(ctx, RSX_ERR_ARG, "unknown generator");
+    if (gen == RSX_GEN_STEP && !(param >= 1.0)) return fail(ctx, RSX_ERR_ARG, "step generator needs param >= 1");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    uint64_t blocks = (n + 255) / 256;
+    const uint64_t cap = (uint64_t)ctx->num_cu * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(rsx_generate_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, static_cast<uint8_t*>(d_data),
+                       (uint64_t)n, L->elem_bytes, L->key_offset, L->key_bytes, gen, seed, param, index_base);
+    RSX_HIP(hipGetLastError());
+    return RSX_OK;
+} catch (...) {
+    return RSX_ERR_HIP;
+}
+
+int rsx_verify_device(rsx_ctx* ctx, const void* d_data, size_t n, const rsx_layout* L, uint64_t* d_out,
+                      void* stream) try {
+    if (!ctx) return RSX_ERR_ARG;
+    if (!layout_ok(L)) return fail(ctx, RSX_ERR_ARG, "invalid rsx_layout");
+    if (!d_out) return fail(ctx, RSX_ERR_ARG, "null pointer");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    RSX_HIP(hipMemsetAsync(d_out, 0, 3 * sizeof(uint64_t), st));
+    if (n == 0) return RSX_OK;
+    if (!d_data) return fail(ctx, RSX_ERR_ARG, "null pointer");
+    uint64_t blocks = (n + 255) / 256;
+    const uint64_t cap = (uint64_t)ctx->num_cu * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(rsx_verify_kernel, dim3((uint32_t)blocks), dim3(256), 0, st,
+                       static_cast<const uint8_t*>(d_data), (uint64_t)n, L->elem_bytes, L->key_offset, L->key_bytes,
+                       L->key_kind, d_out);
+    RSX_HIP(hipGetLastError());
+    return RSX_OK;
+} catch (...) {
+    return RSX_ERR_HIP;
+}
+
+}  // extern "C"
