@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""bench.py -- Gkeys/s of the MI355X LSD radix sort on BASELINE.json's configurations.
+
+A "step" is one full sort (all D passes of the hot path) of one batch of synthetic
+input already resident in HBM.  K steps sort K different pre-generated batches, so
+every timed sort sees unsorted data and generation stays outside the timed region.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Prints ONE JSON line on rank 0 (contract in the round prompt): `value` = Gkeys/s of the
+whole job; `roofline` = dominant kernel (rsx_onesweep_kernel, one launch = one pass,
+algorithmic bytes 2*n*s per launch) timed with HIP events on its own launch stream over
+the timed region; `cpu_baseline` = the oracle (thread-parallel C restatement of the
+reference, oracle/rsx_oracle.c) timed on this host's cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+# name -> (type, log2 n per GPU, generator, param, description)
+WORKLOADS = {
+    "c2-256m-u32": ("u32", 28, "uniform", 0.0, "256M u32 uniform keys, 8-bit radix (BASELINE.json configs[1])"),
+    "target-1b-u32": ("u32", 30, "uniform", 0.0, "1B u32 uniform keys (north-star target)"),
+    "c3-1b-u64": ("u64", 30, "uniform", 0.0, "1B u64 uniform keys, 8 passes (configs[2])"),
+    "c4-slice-512m-u32": ("u32", 29, "uniform", 0.0, "2^29 u32 per GPU (configs[3] slice)"),
+    "c5-slice-128m-pairs-zipf": ("(u64,u64)", 27, "zipf", 1.0, "2^27 (u64,u64) Zipf pairs per GPU (configs[4] slice)"),
+    "zipf-256m-u32": ("u32", 28, "zipf", 1.0, "256M u32 Zipf(s=1) keys"),
+    "step16-256m-u32": ("u32", 28, "step", 16.0, "256M u32 step-uniform(16) keys"),
+    "zipf-256m-u64": ("u64", 28, "zipf", 1.0, "256M u64 Zipf(s=1) keys"),
+    "pairs-256m-u32u32": ("(u32,u32)", 28, "uniform", 0.0, "256M (u32,u32) pairs (reference bench type, main.rs:112)"),
+    "pairs-128m-u64u64": ("(u64,u64)", 27, "uniform", 0.0, "128M (u64,u64) pairs (reference bench type, main.rs:123)"),
+}
+EXTRA_DEFAULT = ["target-1b-u32", "c3-1b-u64", "zipf-256m-u32", "step16-256m-u32"]
+
+
+def digits_for(rs, t):
+    if t.startswith("("):
+        k, p = t[1:-1].split(",")
+        return rs.tuple_of(k, int(p[1:]) // 8)
+    return rs.PRIMITIVES[t]
+
+
+def gen_id(rs, name):
+    return {"uniform": rs.GEN_UNIFORM, "zipf": rs.GEN_ZIPF, "step": rs.GEN_STEP}[name]
+
+
+def run_single(rs, torch, ctx, wl, steps, warmup, seed0=0x5EED0000, profile=True):
+    """Times `steps` sorts of `steps` different batches on the current device. Returns dict."""
+    t, logn, gen, param, _ = WORKLOADS[wl]
+    d = digits_for(rs, t)
+    n = 1 << logn
+    nbytes = n * d.elem_bytes
+    free, _total = torch.cuda.mem_get_info()
+    pool = max(1, min(steps, int((free * 0.8 - nbytes) // nbytes)))
+    bufs = [torch.empty(nbytes, dtype=torch.uint8, device="cuda") for _ in range(pool)]
+    tmp = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    ctx.reserve(n, d)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def fill(i, b):
+        ctx.generate_device(b.data_ptr(), n, d, gen_id(rs, gen), seed0 + i, param, 0, stream)
+
+    for i in range(warmup):
+        fill(1000 + i, bufs[0])
+        ctx.sort_device(bufs[0].data_ptr(), tmp.data_ptr(), n, d, stream)
+    done = 0
+    total_ms = 0.0
+    prof_tot = {"sweep": [0.0, 0], "hist": [0.0, 0]}
+    while done < steps:  # pool-sized rounds (pool == steps unless memory is short)
+        k = min(pool, steps - done)
+        for i in range(k):
+            fill(done + i, bufs[i])
+        torch.cuda.synchronize()
+        if profile:
+            ctx.profile(True)
+        t0 = time.perf_counter()
+        for i in range(k):
+            ctx.sort_device(bufs[i].data_ptr(), tmp.data_ptr(), n, d, stream)
+        torch.cuda.synchronize()
+        total_ms += (time.perf_counter() - t0) * 1e3
+        if profile:
+            pr = ctx.profile_read()
+            ctx.profile(False)
+            for kname in prof_tot:
+                prof_tot[kname][0] += pr[kname][0]
+                prof_tot[kname][1] += pr[kname][1]
+        done += k
+    ctx.check()
+    # untimed sanity: last batch is sorted and is a permutation of its input
+    out = torch.zeros(3, dtype=torch.int64, device="cuda")
+    ctx.verify_device(bufs[k - 1].data_ptr(), n, d, out.data_ptr(), stream)
+    v = out.cpu().tolist()
+    assert v[0] == 0 and v[2] == 0, f"bench output not sorted/stable: {v}"
+    del bufs, tmp
+    torch.cuda.empty_cache()
+    ms = total_ms / steps
+    D = d.key_bytes
+    res = {
+        "workload": wl, "type": t, "n": n, "elem_bytes": d.elem_bytes, "passes": D,
+        "ms_per_sort": ms, "gkeys_per_s": n / ms / 1e6,
+        "algorithmic_gbps": D * 2 * n * d.elem_bytes / ms / 1e6,
+        "frac_of_hbm_peak": D * 2 * n * d.elem_bytes / ms / 1e6 / HBM_PEAK_GBPS,
+    }
+    if profile and prof_tot["sweep"][1]:
+        sw_ms = prof_tot["sweep"][0] / prof_tot["sweep"][1]
+        res["sweep_ms_per_launch"] = sw_ms
+        res["sweep_launches"] = prof_tot["sweep"][1]
+        res["sweep_gbps"] = 2 * n * d.elem_bytes / sw_ms / 1e6
+        if prof_tot["hist"][1]:
+            res["hist_ms_per_launch"] = prof_tot["hist"][0] / prof_tot["hist"][1]
+    return res
+
+
+def cpu_baseline(t_name, n_full, target_seconds=15.0):
+    """The oracle (port of mod.rs:61-176) on this host's cores; protocol of main.rs:26-44:
+    mean of 5 runs on fresh data, timed region = the sort call incl. temp alloc + page touch."""
+    import numpy as np
+    from oracle import oracle
+    oracle.build()
+    es, kb = {"u32": (4, 4), "u64": (8, 8), "(u64,u64)": (16, 8), "(u32,u32)": (8, 4)}[t_name]
+    lay = oracle.Layout(es, 0, kb, 0)
+    cores = os.cpu_count() or 1
+    rng = np.random.default_rng(1)
+
+    def one(n):
+        raw = rng.integers(0, 256, size=n * es, dtype=np.uint8)
+        if es != kb:
+            raw.reshape(n, es)[:, kb:] = 0  # payload 0, like KeyUniform (distr.rs:42-52)
+        t0 = time.perf_counter()
+        oracle.sort_parallel_inplace(raw, lay, cores)
+        return time.perf_counter() - t0
+
+    n_cal = 1 << 22
+    rate = n_cal / one(n_cal)  # keys/s
+    n = int(min(n_full, max(1 << 22, rate * target_seconds / 5)))
+    n = 1 << (n.bit_length() - 1)
+    runs = [one(n) for _ in range(5)]
+    mean = sum(runs) / len(runs)
+    return {"value": n / mean / 1e9, "unit": "Gkeys/s", "cores": cores, "kind": "port",
+            "sample": f"{n} {t_name} uniform keys (2^{n.bit_length()-1}), mean of 5 runs, {cores} threads, "
+                      f"timed like main.rs:32-34 (temp alloc + page touch inside)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2-256m-u32", choices=sorted(WORKLOADS))
+    ap.add_argument("--extra", default=",".join(EXTRA_DEFAULT),
+                    help="comma list of further workloads measured (3 steps each) and reported under 'extra' at N=1; '' = none")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import radix_sort_amd as rs
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    ctx = rs.default_context(local_rank)
+    t, logn, gen, param, desc = WORKLOADS[args.workload]
+    d = digits_for(rs, t)
+    n = 1 << logn
+
+    if world == 1:
+        res = run_single(rs, torch, ctx, args.workload, args.steps, args.warmup)
+        ms = res["ms_per_sort"]
+        line = {
+            "metric": "Gkeys/sec (u32)" if t == "u32" else f"Gkeys/sec ({t})",
+            "value": res["gkeys_per_s"], "unit": "Gkeys/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u%d" % (8 * d.key_bytes) if t[0] in "u(" else t, "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc}", "n_keys": n, "elem_bytes": d.elem_bytes,
+                       "passes": d.key_bytes, "radix_bits": 8, "generator": gen,
+                       "algorithmic_bytes_per_sort": d.key_bytes * 2 * n * d.elem_bytes,
+                       "whole_sort_algorithmic_gbps": res["algorithmic_gbps"],
+                       "whole_sort_frac_of_hbm_peak": res["frac_of_hbm_peak"]},
+            "roofline": {
+                "bound": "hbm", "kernel": "rsx_onesweep_kernel (one launch = one digit pass)",
+                "achieved": res.get("sweep_gbps"), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": (res.get("sweep_gbps") or 0.0) / HBM_PEAK_GBPS,
+                "algorithmic_bytes_per_launch": 2 * n * d.elem_bytes,
+                "avg_launch_ms": res.get("sweep_ms_per_launch"), "launches_timed": res.get("sweep_launches"),
+                "traffic": None,
+            },
+        }
+        extra = {}
+        for wl in [w for w in args.extra.split(",") if w and w != args.workload]:
+            try:
+                r = run_single(rs, torch, ctx, wl, 3, 1)
+                extra[wl] = {k: r[k] for k in ("n", "type", "ms_per_sort", "gkeys_per_s", "algorithmic_gbps",
+                                               "frac_of_hbm_peak") if k in r}
+                extra[wl]["sweep_gbps"] = r.get("sweep_gbps")
+            except Exception as e:  # noqa: BLE001  (an extra must never kill the headline)
+                extra[wl] = {"error": repr(e)}
+        if extra:
+            line["extra"] = extra
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(t if t in ("u32", "u64", "(u64,u64)", "(u32,u32)") else "u32", n)
+        print(json.dumps(line), flush=True)
+        return
+
+    # ---- N > 1: one slice per rank, per-pass bucket exchange over RCCL ---------------------
+    import torch.distributed as dist
+    from radix_sort_amd.sharded import ShardedRadixSort
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    sorter = ShardedRadixSort()
+    nbytes = n * d.elem_bytes
+    stream = torch.cuda.current_stream().cuda_stream
+    pool = args.steps
+    bufs = [torch.empty(nbytes, dtype=torch.uint8, device="cuda") for _ in range(pool)]
+    n_per_rank = [n] * world
+
+    def fill(i, b):
+        ctx.generate_device(b.data_ptr(), n, d, gen_id(rs, gen), 0x5EED0000 + i, param, rank * n, stream)
+
+    wbuf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    for i in range(args.warmup):
+        fill(1000 + i, wbuf)
+        sorter.sort(wbuf, d, n_per_rank)
+    for i in range(pool):
+        fill(i, bufs[i])
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        sorter.sort(bufs[i], d, n_per_rank)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    # untimed global order check: local order + boundaries between ranks
+    out = torch.zeros(3, dtype=torch.int64, device="cuda")
+    ctx.verify_device(bufs[-1].data_ptr(), n, d, out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert out[0].item() == 0, "sharded bench output not sorted"
+    ms = el.item() * 1e3 / args.steps
+    total = n * world
+    if rank == 0:
+        line = {
+            "metric": "Gkeys/sec (u32)" if t == "u32" else f"Gkeys/sec ({t})",
+            "value": total / ms / 1e6, "unit": "Gkeys/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u%d" % (8 * d.key_bytes) if t[0] in "u(" else t, "data": "synthetic",
+            "config": {"workload": f"{args.workload} per GPU x {world}: {desc}", "n_keys": total,
+                       "n_keys_per_gpu": n, "elem_bytes": d.elem_bytes, "passes": d.key_bytes, "radix_bits": 8,
+                       "generator": gen, "exchange": "per-pass all-gather(256 x u64) + all-to-all-v (RCCL)"},
+            "roofline": {"bound": "hbm", "achieved": d.key_bytes * 2 * total * d.elem_bytes / ms / 1e6,
+                         "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
+                         "frac": d.key_bytes * 2 * total * d.elem_bytes / ms / 1e6 / (HBM_PEAK_GBPS * world),
+                         "traffic": None, "note": "whole-job algorithmic bytes / wall time (exchange included)"},
+        }
+        print(json.dumps(line), flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -77,6 +77,15 @@ int rsx_ctx_reserve(rsx_ctx *ctx, size_t n, const rsx_layout *layout);
  * reference panics on worker failure, mod.rs:106; across a C ABI that becomes
  * a status).  rsx_sort_host calls it itself. */
 int rsx_ctx_check(rsx_ctx *ctx, void *stream);
+/* Per-launch timing with HIP events on the launch stream (measurement only).
+ * rsx_ctx_profile(ctx, 1) clears the counters and makes every later kernel
+ * launch of this context record a start/stop event pair around itself;
+ * rsx_ctx_profile(ctx, 0) stops recording.  rsx_ctx_profile_read waits for the
+ * recorded events and returns, per kernel kind, the summed duration in
+ * milliseconds and the number of launches (arrays of RSX_PROF_KINDS). */
+enum { RSX_PROF_HIST = 0, RSX_PROF_SCAN = 1, RSX_PROF_SWEEP = 2, RSX_PROF_OTHER = 3, RSX_PROF_KINDS = 4 };
+int rsx_ctx_profile(rsx_ctx *ctx, int enable);
+int rsx_ctx_profile_read(rsx_ctx *ctx, double *ms, uint64_t *launches);
 /* Last error text for this context (never NULL). */
 const char *rsx_last_error(const rsx_ctx *ctx);
 const char *rsx_strerror(int status);

@@ -126,17 +126,14 @@ typedef struct {
     uint8_t *derand;  /* 256 * 96 * s bytes, thread-private (mod.rs:126-129) */
 } orc_job;
 
-static void *orc_count_worker(void *arg) { /* mod.rs:94-100 */
-    orc_job *j = (orc_job *)arg;
-    const size_t s = j->L->elem_bytes;
+/* Bodies are always-inlined with a constant element size for the common sizes so the
+ * per-element memcpy becomes a register move (the Rust original is monomorphised per T). */
+static inline __attribute__((always_inline)) void orc_count_body(orc_job *j, const size_t s) { /* mod.rs:94-100 */
     memset(j->hist, 0, sizeof j->hist);
     for (size_t i = j->begin; i < j->end; ++i) j->hist[orc_digit(j->src + i * s, j->L, j->digit)]++;
-    return NULL;
 }
 
-static void *orc_scatter_worker(void *arg) { /* mod.rs:125-166 */
-    orc_job *j = (orc_job *)arg;
-    const size_t s = j->L->elem_bytes;
+static inline __attribute__((always_inline)) void orc_scatter_body(orc_job *j, const size_t s) { /* mod.rs:125-166 */
     size_t sizes[256] = {0};
     for (size_t i = j->begin; i < j->end; ++i) {
         const uint8_t *e = j->src + i * s;
@@ -152,6 +149,27 @@ static void *orc_scatter_worker(void *arg) { /* mod.rs:125-166 */
     for (int v = 0; v < 256; ++v) /* :155-165 */
         if (sizes[v] > 0)
             memcpy(j->dst + j->hist[v] * s, j->derand + (size_t)v * ORC_BUFFER_SIZE * s, sizes[v] * s);
+}
+
+#define ORC_BY_SIZE(BODY, j)                \
+    switch ((j)->L->elem_bytes) {           \
+    case 1: BODY(j, 1); break;              \
+    case 2: BODY(j, 2); break;              \
+    case 4: BODY(j, 4); break;              \
+    case 8: BODY(j, 8); break;              \
+    case 16: BODY(j, 16); break;            \
+    default: BODY(j, (j)->L->elem_bytes);   \
+    }
+
+static void *orc_count_worker(void *arg) {
+    orc_job *j = (orc_job *)arg;
+    ORC_BY_SIZE(orc_count_body, j)
+    return NULL;
+}
+
+static void *orc_scatter_worker(void *arg) {
+    orc_job *j = (orc_job *)arg;
+    ORC_BY_SIZE(orc_scatter_body, j)
     return NULL;
 }
 

@@ -9,13 +9,15 @@ from . import _build
 
 # every symbol include/rsx.h declares
 SYMBOLS = [
-    "rsx_ctx_create", "rsx_ctx_destroy", "rsx_ctx_reserve", "rsx_ctx_check", "rsx_last_error",
+    "rsx_ctx_create", "rsx_ctx_destroy", "rsx_ctx_reserve", "rsx_ctx_check", "rsx_ctx_profile", "rsx_ctx_profile_read",
+    "rsx_last_error",
     "rsx_strerror", "rsx_version", "rsx_sort_device", "rsx_sort_host", "rsx_histogram_device",
     "rsx_partition_device", "rsx_segmented_copy_device", "rsx_generate_device", "rsx_verify_device",
 ]
 
 OK, ERR_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM, ERR_NODEVICE, ERR_WORKSPACE, ERR_INTERNAL = 0, -1, -2, -3, -4, -5, -6, -7
 KEY_UNSIGNED, KEY_SIGNED, KEY_FLOAT = 0, 1, 2
+PROF_HIST, PROF_SCAN, PROF_SWEEP, PROF_OTHER, PROF_KINDS = 0, 1, 2, 3, 4
 GEN_UNIFORM, GEN_ZIPF, GEN_STEP, GEN_SORTED, GEN_REVERSED, GEN_CONSTANT = 0, 1, 2, 3, 4, 5
 
 
@@ -62,6 +64,8 @@ def load():
     L.rsx_ctx_destroy.argtypes = [vp]
     L.rsx_ctx_reserve.argtypes = [vp, sz, lp]
     L.rsx_ctx_check.argtypes = [vp, vp]
+    L.rsx_ctx_profile.argtypes = [vp, i]
+    L.rsx_ctx_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
     L.rsx_last_error.argtypes = [vp]
     L.rsx_last_error.restype = ctypes.c_char_p
     L.rsx_strerror.argtypes = [i]

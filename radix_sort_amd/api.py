@@ -136,6 +136,18 @@ class Context:
     def check(self, stream: int = 0):
         self._check(self._L.rsx_ctx_check(self._h, stream))
 
+    def profile(self, enable: bool):
+        """Per-launch HIP-event timing on/off (rsx_ctx_profile); enabling clears the counters."""
+        self._check(self._L.rsx_ctx_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self):
+        """-> {kind: (total_ms, launches)} for kinds hist/scan/sweep/other."""
+        ms = (ctypes.c_double * _lib.PROF_KINDS)()
+        cnt = (ctypes.c_uint64 * _lib.PROF_KINDS)()
+        self._check(self._L.rsx_ctx_profile_read(self._h, ms, cnt))
+        names = ("hist", "scan", "sweep", "other")
+        return {names[k]: (ms[k], int(cnt[k])) for k in range(_lib.PROF_KINDS)}
+
     def sort_device(self, d_data: int, d_tmp: int, n: int, d: RadixDigits, stream: int = 0):
         lay = d.layout()
         self._check(self._L.rsx_sort_device(self._h, d_data, d_tmp, n, ctypes.byref(lay), stream))

@@ -11,6 +11,8 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "../../include/rsx.h"
 
@@ -29,6 +31,12 @@ struct rsx_ctx {
     void* host_buf[2] = {nullptr, nullptr};
     size_t host_bytes = 0;
     int num_cu = 256;
+    // per-launch HIP-event timing (rsx_ctx_profile)
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending[RSX_PROF_KINDS];
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_free;
+    double prof_ms[RSX_PROF_KINDS] = {0, 0, 0, 0};
+    uint64_t prof_n[RSX_PROF_KINDS] = {0, 0, 0, 0};
 };
 
 namespace {
@@ -53,6 +61,30 @@ int fail(rsx_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
         hipError_t _e = (call);                                         \
         if (_e != hipSuccess) return fail(ctx, RSX_ERR_HIP, #call, _e); \
     } while (0)
+
+// Records a start/stop event pair around one launch when profiling is on.
+struct LaunchTimer {
+    rsx_ctx* c;
+    int kind;
+    hipStream_t st;
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    LaunchTimer(rsx_ctx* ctx, int k, hipStream_t s) : c(ctx), kind(k), st(s) {
+        if (!c->prof) return;
+        if (!c->prof_free.empty()) {
+            ev = c->prof_free.back();
+            c->prof_free.pop_back();
+        } else if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) {
+            ev = {nullptr, nullptr};
+            return;
+        }
+        (void)hipEventRecord(ev.first, st);
+    }
+    ~LaunchTimer() {
+        if (!ev.first) return;
+        (void)hipEventRecord(ev.second, st);
+        c->prof_pending[kind].push_back(ev);
+    }
+};
 
 bool layout_ok(const rsx_layout* L) {
     if (!L) return false;
@@ -128,6 +160,7 @@ int launch_hist(rsx_ctx* ctx, const void* src, size_t n, const rsx_layout* L, ui
     const uint64_t cap = (uint64_t)ctx->num_cu * 8;
     if (blocks > cap) blocks = cap;
     if (blocks == 0) blocks = 1;
+    LaunchTimer lt(ctx, RSX_PROF_HIST, st);
     hipLaunchKernelGGL((rsx_hist_kernel<ES>), dim3((uint32_t)blocks), dim3(512), nd * RADIX * sizeof(uint32_t), st,
                        static_cast<const Elem<ES>*>(src), (uint64_t)n, ghist, L->key_offset, L->key_bytes,
                        L->key_kind, d0, nd);
@@ -153,6 +186,7 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, size_t n, const rsx
     a.error = error_of(ctx);
     a.spec = make_spec(L, digit);
     const size_t lds = (size_t)TILE * ES + RADIX * sizeof(uint64_t) + (SWEEP_WG / WAVE) * RADIX * sizeof(uint32_t) + 32;
+    LaunchTimer lt(ctx, RSX_PROF_SWEEP, st);
     hipLaunchKernelGGL((rsx_onesweep_kernel<ES, KPT, SWEEP_WG, S>), dim3((uint32_t)ntiles), dim3(SWEEP_WG), lds, st,
                        a);
     RSX_HIP(hipGetLastError());
@@ -273,6 +307,12 @@ int rsx_ctx_destroy(rsx_ctx* ctx) try {
         if (ctx->aux) (void)hipFree(ctx->aux);
         for (void* p : ctx->host_buf)
             if (p) (void)hipFree(p);
+        for (int k = 0; k < RSX_PROF_KINDS; ++k)
+            for (auto& e : ctx->prof_pending[k]) ctx->prof_free.push_back(e);
+        for (auto& e : ctx->prof_free) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
     }
     delete ctx;
     return RSX_OK;
@@ -307,6 +347,45 @@ int rsx_ctx_check(rsx_ctx* ctx, void* stream) try {
     return RSX_ERR_HIP;
 }
 
+int rsx_ctx_profile(rsx_ctx* ctx, int enable) try {
+    if (!ctx) return RSX_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (enable) {
+        for (int k = 0; k < RSX_PROF_KINDS; ++k) {
+            for (auto& e : ctx->prof_pending[k]) ctx->prof_free.push_back(e);
+            ctx->prof_pending[k].clear();
+            ctx->prof_ms[k] = 0;
+            ctx->prof_n[k] = 0;
+        }
+    }
+    ctx->prof = enable != 0;
+    return RSX_OK;
+} catch (...) {
+    return RSX_ERR_NOMEM;
+}
+
+int rsx_ctx_profile_read(rsx_ctx* ctx, double* ms, uint64_t* launches) try {
+    if (!ctx || !ms || !launches) return RSX_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    for (int k = 0; k < RSX_PROF_KINDS; ++k) {
+        for (auto& e : ctx->prof_pending[k]) {
+            RSX_HIP(hipEventSynchronize(e.second));
+            float t = 0;
+            RSX_HIP(hipEventElapsedTime(&t, e.first, e.second));
+            ctx->prof_ms[k] += t;
+            ctx->prof_n[k] += 1;
+            ctx->prof_free.push_back(e);
+        }
+        ctx->prof_pending[k].clear();
+        ms[k] = ctx->prof_ms[k];
+        launches[k] = ctx->prof_n[k];
+    }
+    return RSX_OK;
+} catch (...) {
+    return RSX_ERR_HIP;
+}
+
 int rsx_sort_device(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const rsx_layout* L, void* stream) try {
     int rc = check_common(ctx, L);
     if (rc) return rc;
@@ -326,7 +405,10 @@ int rsx_sort_device(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const rsx
     RSX_HIP(hipMemsetAsync(ghist, 0, (size_t)D * RADIX * sizeof(uint64_t), st));
     rc = hist_dispatch(ctx, d_data, n, L, 0, D, ghist, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(rsx_scan_kernel, dim3(D), dim3(RADIX), 0, st, ghist, (uint64_t*)nullptr);
+    {
+        LaunchTimer lt(ctx, RSX_PROF_SCAN, st);
+        hipLaunchKernelGGL(rsx_scan_kernel, dim3(D), dim3(RADIX), 0, st, ghist, (uint64_t*)nullptr);
+    }
     RSX_HIP(hipGetLastError());
     // pass loop with ping-pong (mod.rs:84-89)
     for (uint32_t d = 0; d < D; ++d) {
@@ -416,7 +498,10 @@ int rsx_partition_device(rsx_ctx* ctx, const void* d_src, void* d_dst, size_t n,
     RSX_HIP(hipMemsetAsync(ghist, 0, RADIX * sizeof(uint64_t), st));
     rc = hist_dispatch(ctx, d_src, n, L, digit, 1, ghist, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(rsx_scan_kernel, dim3(1), dim3(RADIX), 0, st, ghist, d_hist);
+    {
+        LaunchTimer lt(ctx, RSX_PROF_SCAN, st);
+        hipLaunchKernelGGL(rsx_scan_kernel, dim3(1), dim3(RADIX), 0, st, ghist, d_hist);
+    }
     RSX_HIP(hipGetLastError());
     return sweep_dispatch(ctx, d_src, d_dst, n, L, digit, ghist, st);
 } catch (...) {

@@ -1,0 +1,255 @@
+"""GPU: parity of the HIP path (through the C-ABI, librsx.so) with the CPU oracle.
+Bit-exact (integer / byte / index work): np.array_equal on the raw element bytes."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden.npz")
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def rs():
+    import radix_sort_amd as rs
+    return rs
+
+
+@pytest.fixture(scope="module")
+def ctx(rs, torch):
+    return rs.default_context(torch.cuda.current_device())
+
+
+def _digits(rs, t):
+    return rs.RadixDigits(*util.TYPES[t])
+
+
+def _gpu_sort(rs, torch, ctx, raw, d):
+    x = torch.from_numpy(raw.copy()).cuda()
+    rs.radix_sort(x, digits=d)
+    ctx.check()
+    return x.cpu().numpy()
+
+
+EDGE_SIZES = [0, 1, 2, 3, 63, 64, 65, 511, 512, 513, 2047, 2048, 2049, 8191, 8192, 8193, 16385, 100003]
+
+
+@pytest.mark.parametrize("t", list(util.TYPES))
+def test_edge_sizes_uniform(rs, torch, ctx, orc, t):
+    d = _digits(rs, t)
+    lay = orc.Layout(*util.TYPES[t])
+    for n in EDGE_SIZES:
+        raw = util.make_input(t, n, "uniform", seed=1000 + n)
+        assert np.array_equal(_gpu_sort(rs, torch, ctx, raw, d), orc.sort_parallel(raw, lay, 4)), (t, n)
+
+
+@pytest.mark.parametrize("t", list(util.TYPES))
+@pytest.mark.parametrize("dist", util.DISTS)
+def test_distributions(rs, torch, ctx, orc, t, dist):
+    d = _digits(rs, t)
+    lay = orc.Layout(*util.TYPES[t])
+    for n in (777, 50021):
+        raw = util.make_input(t, n, dist, seed=hash((t, dist)) & 0xFFFF)
+        assert np.array_equal(_gpu_sort(rs, torch, ctx, raw, d), orc.sort_parallel(raw, lay, 3)), (t, dist, n)
+
+
+def test_golden_fixtures(rs, torch, ctx):
+    z = np.load(GOLDEN)
+    keys = [k[3:] for k in z.files if k.startswith("in|")]
+    for k in keys:
+        t = k.split("|")[0]
+        got = _gpu_sort(rs, torch, ctx, z["in|" + k], _digits(rs, t))
+        assert np.array_equal(got, z["out|" + k]), k
+
+
+@pytest.mark.parametrize("t", ["u8", "u16", "u32", "u64", "u128", "i32", "f32", "f64", "(u32,u32)", "(u64,u64)"])
+def test_reference_test_size_1e6(rs, torch, ctx, orc, t):
+    """tests.rs shape: 1e6 random elements per type, vs the oracle (not just sortedness)."""
+    d = _digits(rs, t)
+    lay = orc.Layout(*util.TYPES[t])
+    raw = util.make_input(t, 10 ** 6, "uniform", seed=42)
+    assert np.array_equal(_gpu_sort(rs, torch, ctx, raw, d), orc.sort_parallel(raw, lay, 8))
+
+
+def test_config1_1m_u32(rs, torch, ctx, orc):
+    """BASELINE.json configs[0]: 1M u32 uniform keys -- CPU reference path (oracle) vs HIP."""
+    n = 1 << 20
+    raw = util.make_input("u32", n, "uniform", seed=0x5EED0001)
+    lay = orc.Layout(4, 0, 4, 0)
+    exp = orc.sort_parallel(raw, lay, os.cpu_count() or 1)
+    assert np.array_equal(_gpu_sort(rs, torch, ctx, raw, rs.PRIMITIVES["u32"]), exp)
+
+
+def test_stability_heavy_duplicates(rs, torch, ctx, orc):
+    """tuples with few distinct keys: payload (= original index) order must be preserved."""
+    for t in ("(u32,u32)", "(u64,u64)", "(u8,u8)", "(pay32+u32)"):
+        raw = util.make_input(t, 300007, "two", seed=9)
+        lay = orc.Layout(*util.TYPES[t])
+        assert np.array_equal(_gpu_sort(rs, torch, ctx, raw, _digits(rs, t)), orc.sort0(raw, lay)), t
+
+
+def test_idempotent_and_tmp_reuse(rs, torch, ctx):
+    raw = util.make_input("u64", 200000, "uniform", seed=5)
+    x = torch.from_numpy(raw.copy()).cuda()
+    tmp = torch.empty_like(x)
+    rs.radix_sort(x, digits=rs.PRIMITIVES["u64"], tmp=tmp)
+    once = x.clone()
+    rs.radix_sort(x, digits=rs.PRIMITIVES["u64"], tmp=tmp)
+    ctx.check()
+    assert torch.equal(x, once)
+
+
+def test_torch_dtypes_inferred(rs, torch, ctx):
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for dt in (torch.int32, torch.int64, torch.float32, torch.float64, torch.int16, torch.int8, torch.uint8):
+        if dt.is_floating_point:
+            x = torch.randn(100001, generator=g, dtype=dt)
+        else:
+            info = torch.iinfo(dt)
+            x = torch.randint(info.min, info.max, (100001,), generator=g, dtype=torch.int64).to(dt)
+        y = x.cuda()
+        rs.radix_sort(y)
+        ctx.check()
+        assert torch.equal(y.cpu(), torch.sort(x, stable=True).values), dt
+
+
+def test_host_slice_drop_in(rs, torch, ctx, orc):
+    """rsx_sort_host: the literal `&mut [T]` drop-in (H2D -> sort -> D2H)."""
+    a = np.random.default_rng(1).integers(0, 2 ** 32, size=300001, dtype=np.uint32)
+    exp = np.sort(a, kind="stable")
+    rs.radix_sort(a)
+    assert np.array_equal(a, exp)
+    pair = np.dtype([("k", "<u8"), ("v", "<u8")])
+    b = np.zeros(100001, dtype=pair)
+    b["k"] = np.random.default_rng(2).integers(0, 50, size=b.size)
+    b["v"] = np.arange(b.size)
+    exp = b[np.argsort(b["k"], kind="stable")]
+    rs.radix_sort(b)
+    assert np.array_equal(b, exp)
+
+
+def test_histogram_and_partition_pass(rs, torch, ctx, orc):
+    """The per-pass building blocks used by the multi-GPU bucket exchange."""
+    for t in ("u32", "(u64,u64)", "f64"):
+        es, ko, kb, kind = util.TYPES[t]
+        d = _digits(rs, t)
+        lay = orc.Layout(es, ko, kb, kind)
+        raw = util.make_input(t, 70001, "zipf", seed=4)
+        src = torch.from_numpy(raw.copy()).cuda()
+        dst = torch.empty_like(src)
+        hist = torch.zeros(256, dtype=torch.int64, device="cuda")
+        for digit in range(kb):
+            exp, exp_hist = orc.partition_pass(raw, lay, digit)
+            ctx.histogram_device(src.data_ptr(), 70001, d, digit, hist.data_ptr())
+            ctx.check()
+            assert np.array_equal(hist.cpu().numpy().astype(np.uint64), exp_hist), (t, digit)
+            hist.zero_()
+            ctx.partition_device(src.data_ptr(), dst.data_ptr(), 70001, d, digit, hist.data_ptr())
+            ctx.check()
+            assert np.array_equal(dst.cpu().numpy(), exp), (t, digit)
+            assert np.array_equal(hist.cpu().numpy().astype(np.uint64), exp_hist), (t, digit)
+
+
+def test_segmented_copy(rs, torch, ctx):
+    src = torch.arange(10000, dtype=torch.int64, device="cuda")
+    dst = torch.full((10000,), -1, dtype=torch.int64, device="cuda")
+    so = torch.tensor([0, 5000, 100], dtype=torch.int64, device="cuda")
+    do = torch.tensor([7000, 0, 6000], dtype=torch.int64, device="cuda")
+    ln = torch.tensor([3000, 5000, 0], dtype=torch.int64, device="cuda")
+    ctx.segmented_copy_device(src.data_ptr(), dst.data_ptr(), 8, so.data_ptr(), do.data_ptr(), ln.data_ptr(), 3)
+    ctx.check()
+    exp = torch.full((10000,), -1, dtype=torch.int64)
+    exp[7000:10000] = torch.arange(0, 3000)
+    exp[0:5000] = torch.arange(5000, 10000)
+    assert torch.equal(dst.cpu(), exp)
+
+
+def test_errors(rs, torch, ctx):
+    x = torch.zeros(1024, dtype=torch.uint8, device="cuda")
+    with pytest.raises(rs.RsxError):  # 3-byte elements: no kernel
+        rs.radix_sort(x[:1023], digits=rs.RadixDigits(3, 0, 2, 0))
+    with pytest.raises(rs.RsxError):  # key outside the element
+        rs.radix_sort(x, digits=rs.RadixDigits(4, 2, 4, 0))
+    with pytest.raises(rs.RsxError):  # misaligned device pointer
+        rs.radix_sort(x[1:1021], digits=rs.PRIMITIVES["u32"])
+
+
+# ---- full-size configurations (BASELINE.json configs[1], configs[2]) through size-independent
+# ---- properties: sortedness, multiset checksum, stability, all computed on the device.
+def _full_size(rs, torch, ctx, t, n, gen, param=0.0, seed=0x5EED0002):
+    d = _digits(rs, t)
+    x = torch.empty(n * d.elem_bytes, dtype=torch.uint8, device="cuda")
+    tmp = torch.empty_like(x)
+    out = torch.zeros(3, dtype=torch.int64, device="cuda")
+    ctx.generate_device(x.data_ptr(), n, d, gen, seed, param)
+    ctx.verify_device(x.data_ptr(), n, d, out.data_ptr())
+    before = out.cpu().numpy().astype(np.uint64)
+    rs.radix_sort(x, digits=d, tmp=tmp)
+    ctx.check()
+    ctx.verify_device(x.data_ptr(), n, d, out.data_ptr())
+    after = out.cpu().numpy().astype(np.uint64)
+    assert after[0] == 0, f"{after[0]} descents after sort"
+    assert after[1] == before[1], "multiset checksum changed"
+    assert after[2] == 0, f"{after[2]} stability violations"
+    if gen == rs.GEN_UNIFORM and n > 1000:
+        assert before[0] > 0  # the input really was unsorted
+    del x, tmp
+    torch.cuda.empty_cache()
+
+
+def test_config2_256m_u32(rs, torch, ctx):
+    _full_size(rs, torch, ctx, "u32", 1 << 28, rs.GEN_UNIFORM)
+
+
+def test_config3_1b_u64(rs, torch, ctx):
+    _full_size(rs, torch, ctx, "u64", 1 << 30, rs.GEN_UNIFORM, seed=0x5EED0003)
+
+
+def test_target_1b_u32(rs, torch, ctx):
+    _full_size(rs, torch, ctx, "u32", 1 << 30, rs.GEN_UNIFORM, seed=0x5EED0006)
+
+
+def test_pairs_zipf_stability_full_slice(rs, torch, ctx):
+    """configs[4] per-GPU slice: 2^27 (u64 key, u64 payload=index) Zipf-skewed pairs."""
+    _full_size(rs, torch, ctx, "(u64,u64)", 1 << 27, rs.GEN_ZIPF, param=1.0, seed=0x5EED0005)
+
+
+def test_skewed_and_degenerate_large(rs, torch, ctx):
+    for gen, param in ((rs.GEN_STEP, 16.0), (rs.GEN_CONSTANT, 7.0), (rs.GEN_SORTED, 0.0), (rs.GEN_REVERSED, 0.0),
+                       (rs.GEN_ZIPF, 1.0)):
+        _full_size(rs, torch, ctx, "(u32,u32)", (1 << 24) + 12345, gen, param)
+
+
+def test_more_than_2pow30_elements_uses_64bit_status(rs, torch, ctx):
+    """n > 2^30 switches the look-back words to 64 bit; all-equal keys push one digit's
+    prefix past 2^30."""
+    n = (1 << 30) + (1 << 20) + 77
+    _full_size(rs, torch, ctx, "u8", n, rs.GEN_UNIFORM)
+    # all-equal u8 key + 7-byte payload (= original index, wide enough not to wrap)
+    _full_size(rs, torch, ctx, "(u8,[u8;7])", n, rs.GEN_CONSTANT, param=3.0)
+
+
+def test_verify_detects_errors(rs, torch, ctx):
+    """The checker itself: unsorted data and instability must be reported."""
+    d = _digits(rs, "(u32,u32)")
+    n = 100000
+    x = torch.empty(n * 8, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(3, dtype=torch.int64, device="cuda")
+    ctx.generate_device(x.data_ptr(), n, d, rs.GEN_REVERSED, 1)
+    ctx.verify_device(x.data_ptr(), n, d, out.data_ptr())
+    assert out[0].item() == n - 1
+    ctx.generate_device(x.data_ptr(), n, d, rs.GEN_CONSTANT, 1, 5.0)
+    v = x.view(torch.int32).view(n, 2)
+    v[:, 1] = torch.arange(n - 1, -1, -1, dtype=torch.int32, device="cuda")  # payload descending
+    ctx.verify_device(x.data_ptr(), n, d, out.data_ptr())
+    assert out[0].item() == 0 and out[2].item() == n - 1
