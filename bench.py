@@ -101,7 +101,8 @@ def run_single(rs, torch, ctx, wl, steps, warmup, seed0=0x5EED0000, profile=True
     out = torch.zeros(3, dtype=torch.int64, device="cuda")
     ctx.verify_device(bufs[k - 1].data_ptr(), n, d, out.data_ptr(), stream)
     v = out.cpu().tolist()
-    assert v[0] == 0 and v[2] == 0, f"bench output not sorted/stable: {v}"
+    if not os.environ.get("RSX_DEBUG"):  # ablation switches produce wrong output by design
+        assert v[0] == 0 and v[2] == 0, f"bench output not sorted/stable: {v}"
     del bufs, tmp
     torch.cuda.empty_cache()
     ms = total_ms / steps

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -31,6 +32,7 @@ struct rsx_ctx {
     void* host_buf[2] = {nullptr, nullptr};
     size_t host_bytes = 0;
     int num_cu = 256;
+    uint32_t dbg = 0;  // RSX_DEBUG env: timing-only ablation switches for the sweep kernel
     // per-launch HIP-event timing (rsx_ctx_profile)
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending[RSX_PROF_KINDS];
@@ -42,7 +44,7 @@ struct rsx_ctx {
 namespace {
 
 constexpr size_t GHIST_BYTES = 16 * RADIX * sizeof(uint64_t);
-constexpr size_t AUX_BYTES = 2 * GHIST_BYTES + 64;
+constexpr size_t AUX_BYTES = 2 * GHIST_BYTES + 64 + 64;  // + error word block + 8 debug counters
 constexpr int SWEEP_WG = 512;
 
 int fail(rsx_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
@@ -110,17 +112,30 @@ uint32_t elem_align(uint32_t es) {
 bool aligned(const void* p, uint32_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
 // keys per thread by element size: keeps the LDS tile at 32 KiB (ES >= 4)
+#ifndef RSX_KPT4
+#define RSX_KPT4 16
+#endif
 constexpr int kpt_for(int es) {
-    return es <= 4 ? 16 : es == 8 ? 8 : es == 12 ? 5 : es == 16 ? 4 : es == 24 ? 3 : 2;
+    return es <= 4 ? RSX_KPT4 : es == 8 ? 8 : es == 12 ? 5 : es == 16 ? 4 : es == 24 ? 3 : 2;
 }
 uint32_t tile_elems(uint32_t es) { return SWEEP_WG * kpt_for((int)es); }
 
 DigitSpec make_spec(const rsx_layout* L, uint32_t digit) {
     DigitSpec s;
-    s.byte = L->key_offset + digit;
-    s.top_byte = L->key_offset + L->key_bytes - 1;
+    const uint32_t byte = L->key_offset + digit;
+    const uint32_t top = L->key_offset + L->key_bytes - 1;
+    if (L->elem_bytes >= 4) {
+        s.word = byte >> 2;
+        s.shift = 8 * (byte & 3);
+        s.top_word = top >> 2;
+        s.top_shift = 8 * (top & 3) + 7;
+    } else {  // 1- and 2-byte elements live in one register
+        s.word = 0;
+        s.shift = 8 * byte;
+        s.top_word = 0;
+        s.top_shift = 8 * top + 7;
+    }
     s.flip = (L->key_kind != RSX_KEY_UNSIGNED && digit == L->key_bytes - 1) ? 0x80u : 0u;
-    s.is_float = L->key_kind == RSX_KEY_FLOAT;
     return s;
 }
 
@@ -168,7 +183,7 @@ int launch_hist(rsx_ctx* ctx, const void* src, size_t n, const rsx_layout* L, ui
     return RSX_OK;
 }
 
-template <int ES, typename S>
+template <int ES, typename S, bool FLT>
 int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, size_t n, const rsx_layout* L, uint32_t digit,
                    const uint64_t* digit_start, hipStream_t st) {
     constexpr int KPT = kpt_for(ES);
@@ -185,9 +200,11 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, size_t n, const rsx
     a.status = static_cast<char*>(ctx->zero_blk) + 16;
     a.error = error_of(ctx);
     a.spec = make_spec(L, digit);
+    a.dbg = ctx->dbg;
+    a.dbg_cnt = reinterpret_cast<unsigned long long*>(static_cast<char*>(ctx->aux) + 2 * GHIST_BYTES + 64);
     const size_t lds = (size_t)TILE * ES + RADIX * sizeof(uint64_t) + (SWEEP_WG / WAVE) * RADIX * sizeof(uint32_t) + 32;
     LaunchTimer lt(ctx, RSX_PROF_SWEEP, st);
-    hipLaunchKernelGGL((rsx_onesweep_kernel<ES, KPT, SWEEP_WG, S>), dim3((uint32_t)ntiles), dim3(SWEEP_WG), lds, st,
+    hipLaunchKernelGGL((rsx_onesweep_kernel<ES, KPT, SWEEP_WG, S, FLT>), dim3((uint32_t)ntiles), dim3(SWEEP_WG), lds, st,
                        a);
     RSX_HIP(hipGetLastError());
     return RSX_OK;
@@ -196,8 +213,15 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, size_t n, const rsx
 template <int ES>
 int launch_sweep(rsx_ctx* ctx, const void* src, void* dst, size_t n, const rsx_layout* L, uint32_t digit,
                  const uint64_t* digit_start, hipStream_t st) {
-    if (n <= (1ull << 30)) return launch_sweep_t<ES, uint32_t>(ctx, src, dst, n, L, digit, digit_start, st);
-    return launch_sweep_t<ES, uint64_t>(ctx, src, dst, n, L, digit, digit_start, st);
+    const bool small = n <= (1ull << 30);
+    if constexpr (ES >= 4) {  // float keys are 4 or 8 bytes wide
+        if (L->key_kind == RSX_KEY_FLOAT) {
+            if (small) return launch_sweep_t<ES, uint32_t, true>(ctx, src, dst, n, L, digit, digit_start, st);
+            return launch_sweep_t<ES, uint64_t, true>(ctx, src, dst, n, L, digit, digit_start, st);
+        }
+    }
+    if (small) return launch_sweep_t<ES, uint32_t, false>(ctx, src, dst, n, L, digit, digit_start, st);
+    return launch_sweep_t<ES, uint64_t, false>(ctx, src, dst, n, L, digit, digit_start, st);
 }
 
 #define RSX_DISPATCH_ES(es, FN, ...)                           \
@@ -285,6 +309,7 @@ int rsx_ctx_create(int device, rsx_ctx** out) try {
     rsx_ctx* ctx = new (std::nothrow) rsx_ctx();
     if (!ctx) return RSX_ERR_NOMEM;
     ctx->device = device;
+    if (const char* dbg = std::getenv("RSX_DEBUG")) ctx->dbg = (uint32_t)std::strtoul(dbg, nullptr, 0);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
         ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -342,6 +367,20 @@ int rsx_ctx_check(rsx_ctx* ctx, void* stream) try {
         (void)hipMemset(error_of(ctx), 0, sizeof e);
         return fail(ctx, RSX_ERR_INTERNAL, "look-back spin gave up (device protocol error)");
     }
+    return RSX_OK;
+} catch (...) {
+    return RSX_ERR_HIP;
+}
+
+// Diagnostic counters of the sweep kernel (RSX_DEBUG & 0x100); not part of include/rsx.h.
+int rsx_debug_counters(rsx_ctx* ctx, unsigned long long* out8, int reset) try {
+    if (!ctx || !out8 || !ctx->aux) return RSX_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    RSX_HIP(hipDeviceSynchronize());
+    char* p = static_cast<char*>(ctx->aux) + 2 * GHIST_BYTES + 64;
+    RSX_HIP(hipMemcpy(out8, p, 64, hipMemcpyDeviceToHost));
+    if (reset) RSX_HIP(hipMemset(p, 0, 64));
     return RSX_OK;
 } catch (...) {
     return RSX_ERR_HIP;

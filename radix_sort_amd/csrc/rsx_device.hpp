@@ -58,38 +58,45 @@ struct alignas(16) Elem<32> {
 // Which byte of the element is the current digit, and how to map it
 // (radix_digits.rs): all fields are wave-uniform kernel arguments.
 struct DigitSpec {
-    uint32_t byte;      // key_offset + digit index
-    uint32_t top_byte;  // key_offset + key_bytes - 1 (holds the sign bit)
-    uint32_t flip;      // signed keys: 0x80 when byte == top_byte, else 0
-    uint32_t is_float;  // float keys: negative -> ^0xFF, else ^flip
+    uint32_t word;       // dword (ES >= 4) holding the digit byte: (key_offset + digit) / 4
+    uint32_t shift;      // bit offset of the digit byte inside that dword
+    uint32_t top_word;   // dword holding the key's top byte (sign bit)
+    uint32_t top_shift;  // bit offset of the SIGN BIT inside that dword
+    uint32_t flip;       // signed/float keys: 0x80 when the digit is the top byte, else 0
 };
 
 template <int ES>
-__device__ __forceinline__ uint32_t elem_byte(const Elem<ES>& e, uint32_t b) {
-    if constexpr (ES == 1) {
+__device__ __forceinline__ uint32_t elem_word(const Elem<ES>& e, uint32_t wi) {  // wi is wave-uniform
+    if constexpr (ES < 4) {
         return e.w[0];
-    } else if constexpr (ES == 2) {
-        return (e.w[0] >> (8 * b)) & 0xFFu;
     } else {
         constexpr int NW = ES / 4;
         uint32_t word = e.w[0];
-        const uint32_t wi = b >> 2;  // uniform
 #pragma unroll
         for (int i = 1; i < NW; ++i) word = (wi == (uint32_t)i) ? e.w[i] : word;
-        return (word >> (8 * (b & 3))) & 0xFFu;
+        return word;
     }
 }
 
-template <int ES>
+// get_digit of radix_digits.rs on one element.  FLT: f32/f64 keys (:103-124);
+// otherwise unsigned (:7-53, flip == 0) or signed (:55-101, flip == 0x80 on the top byte).
+template <int ES, bool FLT>
 __device__ __forceinline__ uint32_t elem_digit(const Elem<ES>& e, const DigitSpec& s) {
-    uint32_t d = elem_byte<ES>(e, s.byte);
-    if (s.is_float) {  // uniform branch
-        const uint32_t t = elem_byte<ES>(e, s.top_byte);
-        d ^= (t & 0x80u) ? 0xFFu : s.flip;  // radix_digits.rs:106-124
+    uint32_t d = (elem_word<ES>(e, s.word) >> s.shift) & 0xFFu;
+    if constexpr (FLT) {
+        const uint32_t neg = (uint32_t)((int32_t)(elem_word<ES>(e, s.top_word) << (31u - s.top_shift)) >> 31);
+        d ^= (neg & 0xFFu) | (~neg & s.flip);  // negative: flip every bit; else only the sign bit
     } else {
-        d ^= s.flip;  // radix_digits.rs:55-101 (0 for unsigned, :7-53)
+        d ^= s.flip;
     }
     return d;
+}
+
+// generic (slow-path) byte fetch used by the histogram kernel
+template <int ES>
+__device__ __forceinline__ uint32_t elem_byte(const Elem<ES>& e, uint32_t b) {
+    if constexpr (ES < 4) return ((uint32_t)e.w[0] >> (8 * b)) & 0xFFu;
+    else return (elem_word<ES>(e, b >> 2) >> (8 * (b & 3))) & 0xFFu;
 }
 
 // ------------------------------------------------------------ wave helpers --
@@ -103,14 +110,17 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {  // set bits of m belo
 // Lanes of the wave whose 8-bit digit equals mine ("match any" on wave64):
 // 8 ballots, one per digit bit.
 __device__ __forceinline__ uint64_t match_digit(uint32_t d) {
-    uint64_t m = ~0ull;
+    uint32_t lo = ~0u, hi = ~0u;
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const uint64_t bal = __ballot(bit);
-        m &= bit ? bal : ~bal;
+        uint32_t ext = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);  // bit b replicated to 32 bits
+        asm volatile("" : "+v"(ext));  // keep the compare on `ext` (else it is re-derived from d: +1 VALU)
+        const uint64_t bal = __builtin_amdgcn_ballot_w64(ext != 0);
+        // m &= ~(ballot ^ mybit): lanes whose bit b equals mine; one v_bitop3 per half (LUT 0x90)
+        lo = __builtin_amdgcn_bitop3_b32(lo, (uint32_t)bal, ext, 0x90);
+        hi = __builtin_amdgcn_bitop3_b32(hi, (uint32_t)(bal >> 32), ext, 0x90);
     }
-    return m;
+    return ((uint64_t)hi << 32) | lo;
 }
 
 // --------------------------------------------------------------- histogram --
@@ -186,6 +196,10 @@ struct Status<uint64_t> {
     static constexpr int SHIFT = 62;
     static constexpr uint64_t MASK = (1ull << 62) - 1;
 };
+template <typename S>
+__device__ __forceinline__ uint64_t status_index(uint64_t tile, uint32_t digit) {
+    return tile * RADIX + digit;
+}
 
 struct SweepArgs {
     const void* src;
@@ -196,22 +210,25 @@ struct SweepArgs {
     uint32_t* ticket;             // tile ticket counter (zeroed)
     uint32_t* error;              // set non-zero if a bounded spin gave up
     DigitSpec spec;
+    uint32_t dbg;                 // timing-only ablation switches (0 in production)
+    unsigned long long* dbg_cnt;  // [8] diagnostic counters (dbg & 0x100)
 };
 
 // Tile = WG threads x KPT elements, held wave-striped: wave w owns the
 // contiguous segment [w*64*KPT, (w+1)*64*KPT) of the tile and element j of lane
 // l is segment[j*64 + l], so (wave, j, lane) order == input order and ranks
 // computed in that order are stable.
-template <int ES, int KPT, int WG, typename S>
-__global__ __launch_bounds__(WG) void rsx_onesweep_kernel(const SweepArgs a) {
+template <int ES, int KPT, int WG, typename S, bool FLT>
+__global__ __launch_bounds__(WG, (KPT * (ES < 4 ? 4 : ES) > 64 ? 4 : 6)) void rsx_onesweep_kernel(const SweepArgs a) {
     constexpr int NWAVE = WG / WAVE;
     constexpr int TILE = WG * KPT;
     static_assert(WG >= RADIX, "need one thread per digit");
+    static_assert(TILE < (1 << 24), "rank must fit 24 bits");
     using E = Elem<ES>;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     E* s_elems = reinterpret_cast<E*>(smem);                                          // [TILE]
-    uint64_t* s_base = reinterpret_cast<uint64_t*>(smem + (size_t)TILE * sizeof(E));  // [256]
+    uint64_t* s_base = reinterpret_cast<uint64_t*>(smem + (size_t)TILE * sizeof(E));  // [256] byte addresses
     uint32_t* s_whist = reinterpret_cast<uint32_t*>(s_base + RADIX);                  // [NWAVE][256]
     uint32_t* s_misc = s_whist + NWAVE * RADIX;                                       // [8]
 
@@ -219,7 +236,6 @@ __global__ __launch_bounds__(WG) void rsx_onesweep_kernel(const SweepArgs a) {
     const uint32_t lane = tid & 63;
     const uint32_t wave = tid >> 6;
     const E* __restrict__ src = static_cast<const E*>(a.src);
-    E* __restrict__ dst = static_cast<E*>(a.dst);
     S* status = static_cast<S*>(a.status);
 
     // ticket: tiles are handed out in start order, so every lower tile is already running
@@ -231,44 +247,54 @@ __global__ __launch_bounds__(WG) void rsx_onesweep_kernel(const SweepArgs a) {
     const uint64_t tile = s_misc[0];
     const uint64_t tile_base = tile * (uint64_t)TILE;
     const uint64_t remain = a.n - tile_base;
-    const uint32_t valid = remain >= (uint64_t)TILE ? (uint32_t)TILE : (uint32_t)remain;
+    const bool full = remain >= (uint64_t)TILE;
+    const uint32_t valid = full ? (uint32_t)TILE : (uint32_t)remain;
     const uint32_t pad = TILE - valid;  // invalid tail slots, ranked as digit 255 after all valid ones
 
-    // ---- load (wave-striped) ------------------------------------------------
+    // ---- load (wave-striped) + digit + match: all independent -> ILP ------------
     E e[KPT];
-    uint32_t dg[KPT];
+    uint32_t info[KPT];  // digit | below << 8 | count << 16, later digit | rank << 8
     const uint32_t seg = wave * (WAVE * KPT) + lane;
-    if (valid == TILE) {
+    if (full) {  // whole phase duplicated per branch: no pointer phis, immediates fold into the loads
+        const E* p0 = src + tile_base + seg;
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) e[j] = src[tile_base + seg + j * WAVE];
+        for (int j = 0; j < KPT; ++j) e[j] = p0[j * WAVE];
 #pragma unroll
-        for (int j = 0; j < KPT; ++j) dg[j] = elem_digit<ES>(e[j], a.spec);
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t d = elem_digit<ES, FLT>(e[j], a.spec);
+            const uint64_t m = (a.dbg & 8u) ? (uint64_t)d : match_digit(d);
+            info[j] = d | (mbcnt64(m) << 8) | ((uint32_t)__popcll(m) << 16);
+            // two matches in flight hide the SGPR-write -> VALU-read wait states; more only costs VGPRs
+            if (j % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+        }
     } else {
+        const E* p0 = src + tile_base;
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
             const uint32_t p = seg + j * WAVE;
-            if (p < valid) {
-                e[j] = src[tile_base + p];
-                dg[j] = elem_digit<ES>(e[j], a.spec);
-            } else {
-                e[j] = E{};
-                dg[j] = 255u;
-            }
+            e[j] = p0[p < valid ? p : valid - 1];  // clamped: always in bounds
+        }
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            uint32_t d = elem_digit<ES, FLT>(e[j], a.spec);
+            if (seg + j * WAVE >= valid) d = 255u;
+            const uint64_t m = match_digit(d);
+            info[j] = d | (mbcnt64(m) << 8) | ((uint32_t)__popcll(m) << 16);
+            if (j % 2 == 1) __builtin_amdgcn_sched_barrier(0);
         }
     }
 
-    // ---- rank within the wave (stable) ---------------------------------------
-    uint32_t rk[KPT];
+    // ---- rank within the wave (stable): serial over rounds through the wave's LDS counters
+    if (!(a.dbg & 4u))
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
-        const uint64_t m = match_digit(dg[j]);
-        const uint32_t below = mbcnt64(m);
-        const uint32_t cnt = (uint32_t)__popcll(m);
-        const uint32_t prev = my_hist[dg[j]];
+        const uint32_t d = info[j] & 0xFFu;
+        const uint32_t below = (info[j] >> 8) & 0xFFu;
+        const uint32_t prev = my_hist[d];
         __builtin_amdgcn_wave_barrier();
-        if (below == 0) my_hist[dg[j]] = prev + cnt;
+        if (below == 0) my_hist[d] = prev + (info[j] >> 16);
         __builtin_amdgcn_wave_barrier();
-        rk[j] = prev + below;
+        info[j] = d | ((prev + below) << 8);
     }
     __syncthreads();
 
@@ -283,7 +309,7 @@ __global__ __launch_bounds__(WG) void rsx_onesweep_kernel(const SweepArgs a) {
         }
         const uint32_t real = (tid == 255) ? tcount - pad : tcount;
         const S flag = (tile == 0) ? (S)2 : (S)1;
-        __hip_atomic_store(&status[tile * RADIX + tid], (flag << Status<S>::SHIFT) | (S)real, __ATOMIC_RELAXED,
+        __hip_atomic_store(&status[status_index<S>(tile, tid)], (flag << Status<S>::SHIFT) | (S)real, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     }
     // exclusive scan of tcount over the 256 digits -> start of each digit's run in the tile
@@ -313,19 +339,21 @@ __global__ __launch_bounds__(WG) void rsx_onesweep_kernel(const SweepArgs a) {
 
     // ---- reorder the tile in LDS by digit -------------------------------------
 #pragma unroll
-    for (int j = 0; j < KPT; ++j) s_elems[my_hist[dg[j]] + rk[j]] = e[j];
+    for (int j = 0; j < KPT; ++j) s_elems[my_hist[info[j] & 0xFFu] + (info[j] >> 8)] = e[j];
 
     // ---- decoupled look-back: exclusive count of my digit over lower tiles ----
     if (tid < RADIX) {
         uint64_t excl = 0;
-        if (tile > 0) {
+        if (tile > 0 && !(a.dbg & 1u)) {
             uint64_t p = tile - 1;
-            uint32_t spins = 0;
+            uint32_t spins = 0, hops = 0;
             while (true) {
-                const S s = __hip_atomic_load(&status[p * RADIX + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ++hops;
+                const S s = __hip_atomic_load(&status[status_index<S>(p, tid)], __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t f = (uint32_t)(s >> Status<S>::SHIFT);
                 if (f == 0) {
-                    if (++spins > (1u << 24)) {  // bounded: never hang the device
+                    if (++spins > (1u << 22)) {  // bounded: never hang the device
                         atomicExch(a.error, 1u);
                         break;
                     }
@@ -336,23 +364,33 @@ __global__ __launch_bounds__(WG) void rsx_onesweep_kernel(const SweepArgs a) {
                 if (f == 2) break;
                 --p;
             }
+            if ((a.dbg & 0x100u) && tid == 0) {  // diagnostics: hop / stall statistics of digit 0
+                atomicAdd(&a.dbg_cnt[0], 1ull);
+                atomicAdd(&a.dbg_cnt[1], (unsigned long long)hops);
+                atomicAdd(&a.dbg_cnt[2], (unsigned long long)spins);
+                atomicAdd(&a.dbg_cnt[3], (unsigned long long)(tile - p));
+                atomicMax(&a.dbg_cnt[4], (unsigned long long)hops);
+            }
             const uint32_t real = (tid == 255) ? tcount - pad : tcount;
-            __hip_atomic_store(&status[tile * RADIX + tid],
+            __hip_atomic_store(&status[status_index<S>(tile, tid)],
                                ((S)2 << Status<S>::SHIFT) | (S)((excl + real) & (uint64_t)Status<S>::MASK),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        s_base[tid] = a.digit_start[tid] + excl - (uint64_t)tstart;
+        // byte address of LDS slot 0 if it belonged to this digit's run (wrap-safe in u64)
+        s_base[tid] = reinterpret_cast<uint64_t>(a.dst) + (a.digit_start[tid] + excl - (uint64_t)tstart) * ES;
     }
     __syncthreads();
 
     // ---- write runs: consecutive threads -> consecutive addresses within a run -
+    if (!(a.dbg & 2u)) {
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-        const uint32_t p = i * WG + tid;
-        if (p < valid) {
-            const E x = s_elems[p];
-            const uint32_t d = elem_digit<ES>(x, a.spec);
-            dst[s_base[d] + p] = x;
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t p = i * WG + tid;
+            if (full || p < valid) {
+                const E x = s_elems[p];
+                const uint32_t d = elem_digit<ES, FLT>(x, a.spec);
+                *reinterpret_cast<E*>(s_base[d] + (uint64_t)p * ES) = x;
+            }
         }
     }
 }
