@@ -9,7 +9,7 @@ every timed sort sees unsorted data and generation stays outside the timed regio
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 Prints ONE JSON line on rank 0 (contract in the round prompt): `value` = Gkeys/s of the
-whole job; `roofline` = dominant kernel (rsx_onesweep_kernel, one launch = one pass,
+whole job; `roofline` = dominant kernel (rsx_sweep_kernel, one launch = one pass,
 algorithmic bytes 2*n*s per launch) timed with HIP events on its own launch stream over
 the timed region; `cpu_baseline` = the oracle (thread-parallel C restatement of the
 reference, oracle/rsx_oracle.c) timed on this host's cores on a bounded sample.
@@ -192,7 +192,7 @@ def main():
                        "whole_sort_algorithmic_gbps": res["algorithmic_gbps"],
                        "whole_sort_frac_of_hbm_peak": res["frac_of_hbm_peak"]},
             "roofline": {
-                "bound": "hbm", "kernel": "rsx_onesweep_kernel (one launch = one digit pass)",
+                "bound": "hbm", "kernel": "rsx_sweep_kernel (one launch = one digit pass)",
                 "achieved": res.get("sweep_gbps"), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": (res.get("sweep_gbps") or 0.0) / HBM_PEAK_GBPS,
                 "algorithmic_bytes_per_launch": 2 * n * d.elem_bytes,

@@ -19,19 +19,31 @@
 
 using namespace rsx;
 
+namespace {
+// aux block layout (one hipMalloc, zeroed at creation)
+constexpr size_t J_BYTES = (size_t)MAX_REGIONS * RADIX * sizeof(uint64_t);  // one count matrix
+constexpr size_t OFF_J0 = 0;
+constexpr size_t OFF_J1 = OFF_J0 + J_BYTES;
+constexpr size_t OFF_BASE = OFF_J1 + J_BYTES;       // [MAX_REGIONS][256] write cursors
+constexpr size_t OFF_TICKETS = OFF_BASE + J_BYTES;  // [MAX_REGIONS] u32
+constexpr size_t OFF_ERROR = OFF_TICKETS + 64;
+constexpr size_t OFF_DBG = OFF_ERROR + 64;  // 8 diagnostic counters
+constexpr size_t AUX_BYTES = OFF_DBG + 64;
+constexpr int SWEEP_WG = 512;
+}  // namespace
+
 struct rsx_ctx {
     int device = 0;
     std::mutex mu;
     std::string err = "";
-    // block zeroed before every pass: [ticket (16 B)][status words]
-    void* zero_blk = nullptr;
-    size_t zero_bytes = 0;
-    // aux: [ghist 16*256 u64][counts 16*256 u64][error u32 + pad]
-    void* aux = nullptr;
+    void* status = nullptr;  // tile status words, zeroed before every pass
+    size_t status_bytes = 0;
+    char* aux = nullptr;
     // staging for rsx_sort_host
     void* host_buf[2] = {nullptr, nullptr};
     size_t host_bytes = 0;
     int num_cu = 256;
+    uint32_t stagger = 1;  // RSX_STAGGER env (tuning)
     uint32_t dbg = 0;  // RSX_DEBUG env: timing-only ablation switches for the sweep kernel
     // per-launch HIP-event timing (rsx_ctx_profile)
     bool prof = false;
@@ -42,10 +54,6 @@ struct rsx_ctx {
 };
 
 namespace {
-
-constexpr size_t GHIST_BYTES = 16 * RADIX * sizeof(uint64_t);
-constexpr size_t AUX_BYTES = 2 * GHIST_BYTES + 64 + 64;  // + error word block + 8 debug counters
-constexpr int SWEEP_WG = 512;
 
 int fail(rsx_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
     if (c) {
@@ -111,14 +119,31 @@ uint32_t elem_align(uint32_t es) {
 }
 bool aligned(const void* p, uint32_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
-// keys per thread by element size: keeps the LDS tile at 32 KiB (ES >= 4)
+// keys per thread by element size: a power of two, LDS tile of 24..32 KiB for ES >= 4
 #ifndef RSX_KPT4
 #define RSX_KPT4 16
 #endif
-constexpr int kpt_for(int es) {
-    return es <= 4 ? RSX_KPT4 : es == 8 ? 8 : es == 12 ? 5 : es == 16 ? 4 : es == 24 ? 3 : 2;
+constexpr int kpt_for(int es) { return es <= 4 ? RSX_KPT4 : es == 8 ? 8 : es <= 16 ? 4 : 2; }
+constexpr uint32_t tile_elems(int es) { return SWEEP_WG * kpt_for(es); }
+
+uint32_t log2u(uint64_t x) { return 63u - (uint32_t)__builtin_clzll(x); }
+
+// Regions: smallest power-of-two length (>= one tile) that covers n with <= MAX_REGIONS of them.
+RegionGeom make_geom(uint64_t n, uint32_t es) {
+    RegionGeom g;
+    g.n = n;
+    uint32_t k = log2u(tile_elems((int)es));
+    while (((n + (1ull << k) - 1) >> k) > (uint64_t)MAX_REGIONS) ++k;
+    g.region_shift = k;
+    g.num_regions = (uint32_t)((n + (1ull << k) - 1) >> k);
+    if (g.num_regions == 0) g.num_regions = 1;
+    return g;
 }
-uint32_t tile_elems(uint32_t es) { return SWEEP_WG * kpt_for((int)es); }
+uint64_t status_rows(const RegionGeom& g, uint32_t es) {
+    return (uint64_t)g.num_regions << (g.region_shift - log2u(tile_elems((int)es)));
+}
+// chain prefixes are relative to the region: 30 value bits suffice up to 2^30-element regions
+bool status32(const RegionGeom& g) { return g.region_shift <= 30; }
 
 DigitSpec make_spec(const rsx_layout* L, uint32_t digit) {
     DigitSpec s;
@@ -139,89 +164,135 @@ DigitSpec make_spec(const rsx_layout* L, uint32_t digit) {
     return s;
 }
 
-uint64_t* ghist_of(rsx_ctx* c) { return static_cast<uint64_t*>(c->aux); }
-uint64_t* counts_of(rsx_ctx* c) { return reinterpret_cast<uint64_t*>(static_cast<char*>(c->aux) + GHIST_BYTES); }
-uint32_t* error_of(rsx_ctx* c) { return reinterpret_cast<uint32_t*>(static_cast<char*>(c->aux) + 2 * GHIST_BYTES); }
+unsigned long long* J_of(rsx_ctx* c, int which) {
+    return reinterpret_cast<unsigned long long*>(c->aux + (which ? OFF_J1 : OFF_J0));
+}
+uint64_t* base_of(rsx_ctx* c) { return reinterpret_cast<uint64_t*>(c->aux + OFF_BASE); }
+uint32_t* tickets_of(rsx_ctx* c) { return reinterpret_cast<uint32_t*>(c->aux + OFF_TICKETS); }
+uint32_t* error_of(rsx_ctx* c) { return reinterpret_cast<uint32_t*>(c->aux + OFF_ERROR); }
 
-size_t zero_bytes_for(size_t n, uint32_t es) {
-    const uint64_t tile = tile_elems(es);
-    const uint64_t ntiles = (n + tile - 1) / tile;
-    const size_t sw = n <= (1ull << 30) ? 4 : 8;
-    return 16 + (size_t)ntiles * RADIX * sw;
+size_t status_bytes_for(size_t n, uint32_t es) {
+    const RegionGeom g = make_geom(n, es);
+    return (size_t)status_rows(g, es) * RADIX * (status32(g) ? 4 : 8);
 }
 
 int ensure_workspace(rsx_ctx* ctx, size_t n, const rsx_layout* L) {
     if (!ctx->aux) {
-        RSX_HIP(hipMalloc(&ctx->aux, AUX_BYTES));
+        void* p = nullptr;
+        RSX_HIP(hipMalloc(&p, AUX_BYTES));
+        ctx->aux = static_cast<char*>(p);
         RSX_HIP(hipMemset(ctx->aux, 0, AUX_BYTES));
     }
-    const size_t need = zero_bytes_for(n, L->elem_bytes);
-    if (need > ctx->zero_bytes) {
-        if (ctx->zero_blk) RSX_HIP(hipFree(ctx->zero_blk));
-        ctx->zero_blk = nullptr;
-        ctx->zero_bytes = 0;
-        hipError_t e = hipMalloc(&ctx->zero_blk, need);
+    const size_t need = status_bytes_for(n, L->elem_bytes);
+    if (need > ctx->status_bytes) {
+        if (ctx->status) RSX_HIP(hipFree(ctx->status));
+        ctx->status = nullptr;
+        ctx->status_bytes = 0;
+        hipError_t e = hipMalloc(&ctx->status, need);
         if (e != hipSuccess) return fail(ctx, RSX_ERR_NOMEM, "workspace hipMalloc", e);
-        ctx->zero_bytes = need;
+        ctx->status_bytes = need;
     }
     return RSX_OK;
 }
 
-template <int ES>
-int launch_hist(rsx_ctx* ctx, const void* src, size_t n, const rsx_layout* L, uint32_t d0, uint32_t nd,
-                uint64_t* ghist, hipStream_t st) {
+// ---- count phase of a first pass: J[r][v] for `digit` over the input regions ------------------
+template <int ES, bool FLT>
+int launch_hist_t(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_layout* L, uint32_t digit,
+                  unsigned long long* J, hipStream_t st) {
+    RSX_HIP(hipMemsetAsync(J, 0, J_BYTES, st));
     const uint64_t per_block = 512ull * 16;
-    uint64_t blocks = (n + per_block - 1) / per_block;
-    const uint64_t cap = (uint64_t)ctx->num_cu * 8;
-    if (blocks > cap) blocks = cap;
-    if (blocks == 0) blocks = 1;
+    uint64_t bpr = ((1ull << g.region_shift) + per_block - 1) / per_block;
+    const uint64_t cap = ((uint64_t)ctx->num_cu * 8 + g.num_regions - 1) / g.num_regions;
+    if (bpr > cap) bpr = cap;
+    if (bpr == 0) bpr = 1;
     LaunchTimer lt(ctx, RSX_PROF_HIST, st);
-    hipLaunchKernelGGL((rsx_hist_kernel<ES>), dim3((uint32_t)blocks), dim3(512), nd * RADIX * sizeof(uint32_t), st,
-                       static_cast<const Elem<ES>*>(src), (uint64_t)n, ghist, L->key_offset, L->key_bytes,
-                       L->key_kind, d0, nd);
+    hipLaunchKernelGGL((rsx_hist_kernel<ES, FLT>), dim3((uint32_t)(bpr * g.num_regions)), dim3(512), 0, st,
+                       static_cast<const Elem<ES>*>(src), g, make_spec(L, digit), (uint32_t)bpr, J);
+    RSX_HIP(hipGetLastError());
+    return RSX_OK;
+}
+template <int ES>
+int launch_hist(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_layout* L, uint32_t digit,
+                unsigned long long* J, hipStream_t st) {
+    if constexpr (ES >= 4) {
+        if (L->key_kind == RSX_KEY_FLOAT) return launch_hist_t<ES, true>(ctx, src, g, L, digit, J, st);
+    }
+    return launch_hist_t<ES, false>(ctx, src, g, L, digit, J, st);
+}
+
+// ---- prefix phase ------------------------------------------------------------------------------
+int launch_prefix(rsx_ctx* ctx, const RegionGeom& g, const unsigned long long* J, unsigned long long* jnext,
+                  uint64_t* counts_out, hipStream_t st) {
+    LaunchTimer lt(ctx, RSX_PROF_SCAN, st);
+    hipLaunchKernelGGL(rsx_prefix_kernel, dim3(1), dim3(RADIX), 0, st, J, g.num_regions, base_of(ctx), jnext,
+                       tickets_of(ctx), counts_out);
+    RSX_HIP(hipGetLastError());
+    return RSX_OK;
+}
+
+// ---- scatter phase: one sweep pass -------------------------------------------------------------
+template <int ES, typename S, bool FLT, bool NEXT>
+int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L,
+                   uint32_t digit, unsigned long long* jnext, hipStream_t st) {
+    constexpr int KPT = kpt_for(ES);
+    constexpr int TILE = SWEEP_WG * KPT;
+    const uint64_t rows = status_rows(g, ES);
+    RSX_HIP(hipMemsetAsync(ctx->status, 0, (size_t)rows * RADIX * sizeof(S), st));
+    SweepArgs a;
+    a.src = src;
+    a.dst = dst;
+    a.g = g;
+    a.region_base = base_of(ctx);
+    a.status = ctx->status;
+    a.tickets = tickets_of(ctx);
+    a.jnext = jnext;
+    a.error = error_of(ctx);
+    a.spec = make_spec(L, digit);
+    a.next = make_spec(L, NEXT ? digit + 1 : digit);
+    a.dbg = ctx->dbg;
+    a.stagger = ctx->stagger;
+    a.dbg_cnt = reinterpret_cast<unsigned long long*>(ctx->aux + OFF_DBG);
+    const size_t lds = (size_t)TILE * ES + (SWEEP_WG / WAVE) * RADIX * sizeof(uint16_t) +
+                       (NEXT ? (size_t)MAX_REGIONS * RADIX * sizeof(uint32_t) : 0) + 64;
+    auto kern = rsx_sweep_kernel<ES, KPT, SWEEP_WG, S, FLT, NEXT>;
+    static int occ = 0;  // per instantiation: resident workgroups per CU for this kernel
+    if (occ == 0) {
+        int o = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kern, SWEEP_WG, lds) != hipSuccess || o < 1) o = 2;
+        occ = o;
+    }
+    // persistent workgroups; correctness does not need them co-resident (a workgroup only
+    // ever waits for tiles whose tickets were drawn earlier, by workgroups already running)
+    const uint64_t total_tiles = (g.n + TILE - 1) / TILE + g.num_regions;
+    uint64_t grid = (uint64_t)ctx->num_cu * occ;
+    if (grid > total_tiles) grid = total_tiles;
+    if (ctx->dbg & 0x200u) std::fprintf(stderr, "[rsx] sweep ES=%d NEXT=%d occ=%d grid=%llu lds=%zu tiles=%llu regions=%u\n", ES, (int)NEXT, occ, (unsigned long long)grid, lds, (unsigned long long)total_tiles, g.num_regions);
+    if (const char* o = std::getenv("RSX_OCC")) grid = (uint64_t)ctx->num_cu * std::atoi(o);
+    LaunchTimer lt(ctx, RSX_PROF_SWEEP, st);
+    hipLaunchKernelGGL(kern, dim3((uint32_t)grid), dim3(SWEEP_WG), lds, st, a);
     RSX_HIP(hipGetLastError());
     return RSX_OK;
 }
 
 template <int ES, typename S, bool FLT>
-int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, size_t n, const rsx_layout* L, uint32_t digit,
-                   const uint64_t* digit_start, hipStream_t st) {
-    constexpr int KPT = kpt_for(ES);
-    constexpr int TILE = SWEEP_WG * KPT;
-    const uint64_t ntiles = (n + TILE - 1) / TILE;
-    const size_t zb = 16 + (size_t)ntiles * RADIX * sizeof(S);
-    RSX_HIP(hipMemsetAsync(ctx->zero_blk, 0, zb, st));
-    SweepArgs a;
-    a.src = src;
-    a.dst = dst;
-    a.n = n;
-    a.digit_start = digit_start;
-    a.ticket = static_cast<uint32_t*>(ctx->zero_blk);
-    a.status = static_cast<char*>(ctx->zero_blk) + 16;
-    a.error = error_of(ctx);
-    a.spec = make_spec(L, digit);
-    a.dbg = ctx->dbg;
-    a.dbg_cnt = reinterpret_cast<unsigned long long*>(static_cast<char*>(ctx->aux) + 2 * GHIST_BYTES + 64);
-    const size_t lds = (size_t)TILE * ES + RADIX * sizeof(uint64_t) + (SWEEP_WG / WAVE) * RADIX * sizeof(uint32_t) + 32;
-    LaunchTimer lt(ctx, RSX_PROF_SWEEP, st);
-    hipLaunchKernelGGL((rsx_onesweep_kernel<ES, KPT, SWEEP_WG, S, FLT>), dim3((uint32_t)ntiles), dim3(SWEEP_WG), lds, st,
-                       a);
-    RSX_HIP(hipGetLastError());
-    return RSX_OK;
+int launch_sweep_n(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L,
+                   uint32_t digit, unsigned long long* jnext, hipStream_t st) {
+    if (jnext) return launch_sweep_t<ES, S, FLT, true>(ctx, src, dst, g, L, digit, jnext, st);
+    return launch_sweep_t<ES, S, FLT, false>(ctx, src, dst, g, L, digit, jnext, st);
 }
 
 template <int ES>
-int launch_sweep(rsx_ctx* ctx, const void* src, void* dst, size_t n, const rsx_layout* L, uint32_t digit,
-                 const uint64_t* digit_start, hipStream_t st) {
-    const bool small = n <= (1ull << 30);
+int launch_sweep(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L, uint32_t digit,
+                 unsigned long long* jnext, hipStream_t st) {
+    const bool small = status32(g);
     if constexpr (ES >= 4) {  // float keys are 4 or 8 bytes wide
         if (L->key_kind == RSX_KEY_FLOAT) {
-            if (small) return launch_sweep_t<ES, uint32_t, true>(ctx, src, dst, n, L, digit, digit_start, st);
-            return launch_sweep_t<ES, uint64_t, true>(ctx, src, dst, n, L, digit, digit_start, st);
+            if (small) return launch_sweep_n<ES, uint32_t, true>(ctx, src, dst, g, L, digit, jnext, st);
+            return launch_sweep_n<ES, uint64_t, true>(ctx, src, dst, g, L, digit, jnext, st);
         }
     }
-    if (small) return launch_sweep_t<ES, uint32_t, false>(ctx, src, dst, n, L, digit, digit_start, st);
-    return launch_sweep_t<ES, uint64_t, false>(ctx, src, dst, n, L, digit, digit_start, st);
+    if (small) return launch_sweep_n<ES, uint32_t, false>(ctx, src, dst, g, L, digit, jnext, st);
+    return launch_sweep_n<ES, uint64_t, false>(ctx, src, dst, g, L, digit, jnext, st);
 }
 
 #define RSX_DISPATCH_ES(es, FN, ...)                           \
@@ -237,13 +308,13 @@ int launch_sweep(rsx_ctx* ctx, const void* src, void* dst, size_t n, const rsx_l
         default: return fail(ctx, RSX_ERR_UNSUPPORTED, "element size has no device kernel"); \
     }
 
-int hist_dispatch(rsx_ctx* ctx, const void* src, size_t n, const rsx_layout* L, uint32_t d0, uint32_t nd,
-                  uint64_t* ghist, hipStream_t st) {
-    RSX_DISPATCH_ES(L->elem_bytes, launch_hist, ctx, src, n, L, d0, nd, ghist, st)
+int hist_dispatch(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_layout* L, uint32_t digit,
+                  unsigned long long* J, hipStream_t st) {
+    RSX_DISPATCH_ES(L->elem_bytes, launch_hist, ctx, src, g, L, digit, J, st)
 }
-int sweep_dispatch(rsx_ctx* ctx, const void* src, void* dst, size_t n, const rsx_layout* L, uint32_t digit,
-                   const uint64_t* digit_start, hipStream_t st) {
-    RSX_DISPATCH_ES(L->elem_bytes, launch_sweep, ctx, src, dst, n, L, digit, digit_start, st)
+int sweep_dispatch(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L,
+                   uint32_t digit, unsigned long long* jnext, hipStream_t st) {
+    RSX_DISPATCH_ES(L->elem_bytes, launch_sweep, ctx, src, dst, g, L, digit, jnext, st)
 }
 
 template <int ES>
@@ -310,6 +381,7 @@ int rsx_ctx_create(int device, rsx_ctx** out) try {
     if (!ctx) return RSX_ERR_NOMEM;
     ctx->device = device;
     if (const char* dbg = std::getenv("RSX_DEBUG")) ctx->dbg = (uint32_t)std::strtoul(dbg, nullptr, 0);
+    if (const char* sg = std::getenv("RSX_STAGGER")) ctx->stagger = (uint32_t)std::strtoul(sg, nullptr, 0);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
         ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -328,7 +400,7 @@ int rsx_ctx_destroy(rsx_ctx* ctx) try {
     if (!ctx) return RSX_ERR_ARG;
     {
         DeviceGuard g(ctx->device);
-        if (ctx->zero_blk) (void)hipFree(ctx->zero_blk);
+        if (ctx->status) (void)hipFree(ctx->status);
         if (ctx->aux) (void)hipFree(ctx->aux);
         for (void* p : ctx->host_buf)
             if (p) (void)hipFree(p);
@@ -378,9 +450,8 @@ int rsx_debug_counters(rsx_ctx* ctx, unsigned long long* out8, int reset) try {
     std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard g(ctx->device);
     RSX_HIP(hipDeviceSynchronize());
-    char* p = static_cast<char*>(ctx->aux) + 2 * GHIST_BYTES + 64;
-    RSX_HIP(hipMemcpy(out8, p, 64, hipMemcpyDeviceToHost));
-    if (reset) RSX_HIP(hipMemset(p, 0, 64));
+    RSX_HIP(hipMemcpy(out8, ctx->aux + OFF_DBG, 64, hipMemcpyDeviceToHost));
+    if (reset) RSX_HIP(hipMemset(ctx->aux + OFF_DBG, 0, 64));
     return RSX_OK;
 } catch (...) {
     return RSX_ERR_HIP;
@@ -439,21 +510,18 @@ int rsx_sort_device(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const rsx
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint32_t D = L->key_bytes;  // T::NUMBER_OF_DIGITS
-    uint64_t* ghist = ghist_of(ctx);
-    // count (all digits, one read) + per-digit exclusive scan
-    RSX_HIP(hipMemsetAsync(ghist, 0, (size_t)D * RADIX * sizeof(uint64_t), st));
-    rc = hist_dispatch(ctx, d_data, n, L, 0, D, ghist, st);
+    const RegionGeom geom = make_geom(n, L->elem_bytes);
+    // count phase of pass 0 (mod.rs:90-109); later passes are counted by the sweep before them
+    rc = hist_dispatch(ctx, d_data, geom, L, 0, J_of(ctx, 0), st);
     if (rc) return rc;
-    {
-        LaunchTimer lt(ctx, RSX_PROF_SCAN, st);
-        hipLaunchKernelGGL(rsx_scan_kernel, dim3(D), dim3(RADIX), 0, st, ghist, (uint64_t*)nullptr);
-    }
-    RSX_HIP(hipGetLastError());
     // pass loop with ping-pong (mod.rs:84-89)
     for (uint32_t d = 0; d < D; ++d) {
         const void* src = (d % 2 == 0) ? d_data : d_tmp;
         void* dst = (d % 2 == 0) ? d_tmp : d_data;
-        rc = sweep_dispatch(ctx, src, dst, n, L, d, ghist + (size_t)d * RADIX, st);
+        unsigned long long* jnext = (d + 1 < D) ? J_of(ctx, (d + 1) & 1) : nullptr;
+        rc = launch_prefix(ctx, geom, J_of(ctx, d & 1), jnext, nullptr, st);  // mod.rs:110-120
+        if (rc) return rc;
+        rc = sweep_dispatch(ctx, src, dst, geom, L, d, jnext, st);  // mod.rs:121-168
         if (rc) return rc;
     }
     if (D % 2 == 1)  // odd-D copy-back (mod.rs:170-174)
@@ -508,10 +576,17 @@ int rsx_histogram_device(rsx_ctx* ctx, const void* d_src, size_t n, const rsx_la
     std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard g(ctx->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    RSX_HIP(hipMemsetAsync(d_hist, 0, RADIX * sizeof(uint64_t), st));
-    if (n == 0) return RSX_OK;
+    if (n == 0) {
+        RSX_HIP(hipMemsetAsync(d_hist, 0, RADIX * sizeof(uint64_t), st));
+        return RSX_OK;
+    }
     if (!d_src || !aligned(d_src, elem_align(L->elem_bytes))) return fail(ctx, RSX_ERR_ARG, "bad source pointer");
-    return hist_dispatch(ctx, d_src, n, L, digit, 1, d_hist, st);
+    rc = ensure_workspace(ctx, n, L);
+    if (rc) return rc;
+    const RegionGeom geom = make_geom(n, L->elem_bytes);
+    rc = hist_dispatch(ctx, d_src, geom, L, digit, J_of(ctx, 0), st);
+    if (rc) return rc;
+    return launch_prefix(ctx, geom, J_of(ctx, 0), nullptr, d_hist, st);  // column sums -> d_hist
 } catch (...) {
     return RSX_ERR_HIP;
 }
@@ -533,16 +608,12 @@ int rsx_partition_device(rsx_ctx* ctx, const void* d_src, void* d_dst, size_t n,
         return fail(ctx, RSX_ERR_ARG, "bad device pointer");
     rc = ensure_workspace(ctx, n, L);
     if (rc) return rc;
-    uint64_t* ghist = ghist_of(ctx);
-    RSX_HIP(hipMemsetAsync(ghist, 0, RADIX * sizeof(uint64_t), st));
-    rc = hist_dispatch(ctx, d_src, n, L, digit, 1, ghist, st);
+    const RegionGeom geom = make_geom(n, L->elem_bytes);
+    rc = hist_dispatch(ctx, d_src, geom, L, digit, J_of(ctx, 0), st);
     if (rc) return rc;
-    {
-        LaunchTimer lt(ctx, RSX_PROF_SCAN, st);
-        hipLaunchKernelGGL(rsx_scan_kernel, dim3(1), dim3(RADIX), 0, st, ghist, d_hist);
-    }
-    RSX_HIP(hipGetLastError());
-    return sweep_dispatch(ctx, d_src, d_dst, n, L, digit, ghist, st);
+    rc = launch_prefix(ctx, geom, J_of(ctx, 0), nullptr, d_hist, st);
+    if (rc) return rc;
+    return sweep_dispatch(ctx, d_src, d_dst, geom, L, digit, nullptr, st);
 } catch (...) {
     return RSX_ERR_HIP;
 }

@@ -2,13 +2,14 @@
 //
 // Replaces the per-digit count -> prefix -> scatter loop of the reference
 // (src/radix_sort/mod.rs:84-169) with:
-//   rsx_hist_kernel     one streaming read -> all D 256-bin digit histograms
-//                       (count phase, mod.rs:90-109, for every digit at once)
-//   rsx_scan_kernel     exclusive scan of each 256-bin histogram (mod.rs:110-120
-//                       with one chunk; the chunk-minor part is the look-back)
-//   rsx_onesweep_kernel one pass: tile-local stable ranking with wave64 ballots,
-//                       decoupled look-back across tiles (chunk-minor prefix),
-//                       LDS reorder, coalesced run writes (mod.rs:121-168)
+//   rsx_hist_kernel    count phase (mod.rs:90-109) of the first pass: digit counts per
+//                      region (region == the reference's chunk)
+//   rsx_prefix_kernel  prefix phase (mod.rs:110-120): digit-major, region-minor
+//                      exclusive scan of the count matrix -> write cursors
+//   rsx_sweep_kernel   scatter phase (mod.rs:121-168) of one pass: tile-local stable
+//                      ranking with wave64 ballots, decoupled look-back inside each
+//                      region's chain of tiles, LDS reorder, coalesced run writes;
+//                      counts the NEXT pass's digit per destination region on the way
 // Written for wave64 / 160 KiB LDS / 8 XCDs; no portability layer.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -123,49 +124,77 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+// ----------------------------------------------------------------- regions --
+// Every pass sees its INPUT as up to MAX_REGIONS equal position ranges ("regions"):
+//   region r = elements [r << region_shift, min((r + 1) << region_shift, n)).
+// Regions play the "chunk" of the reference (mod.rs:66-70): a count matrix
+// J[r][v] = number of elements of region r whose digit is v is known BEFORE the pass
+// (count phase, mod.rs:90-109), its digit-major / region-minor exclusive scan gives
+// every region its write cursors (prefix phase, mod.rs:110-120), and inside a region
+// the tiles chain by decoupled look-back.  Splitting the look-back into independent
+// chains matters on this chip: an agent-scope status read is a memory-side round trip
+// (the 8 XCD L2s are not coherent), ~0.5 us under load, and a single chain has ~40
+// tiles in the aggregate-only state at any time -- more status traffic than key traffic.
+constexpr int MAX_REGIONS = 16;
+
+struct RegionGeom {
+    uint64_t n;
+    uint32_t region_shift;  // log2(elements per region): a multiple of the tile size
+    uint32_t num_regions;   // ceil(n >> region_shift), 1..MAX_REGIONS
+};
+
 // --------------------------------------------------------------- histogram --
-// One streaming read of the input; every workgroup keeps ND 256-bin histograms
-// in LDS and flushes them with one 64-bit atomic per non-empty bin.
-// ghist layout: [ND][256] uint64 (digit d0 + k at row k).
-template <int ES>
-__global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restrict__ src, uint64_t n,
-                                                       uint64_t* __restrict__ ghist, uint32_t key_offset,
-                                                       uint32_t key_bytes, uint32_t kind, uint32_t d0,
-                                                       uint32_t nd) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lh[];  // [nd][256]
+// Count phase for ONE digit with chunk == region: J[r][v] for the pass's input.
+// grid = num_regions * blocks_per_region; a block stays inside one region.
+// (Only the first pass of a sort needs this kernel: each sweep pass counts the
+// next pass's digit per destination region while it scatters.)
+template <int ES, bool FLT>
+__global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restrict__ src, RegionGeom g,
+                                                       DigitSpec spec, uint32_t blocks_per_region,
+                                                       unsigned long long* __restrict__ J) {
+    __shared__ uint32_t lh[RADIX];
     const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < nd * RADIX; i += blockDim.x) lh[i] = 0;
+    if (tid < RADIX) lh[tid] = 0;
     __syncthreads();
-    const uint32_t top_byte = key_offset + key_bytes - 1;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + tid; i < n; i += stride) {
-        const Elem<ES> e = src[i];
-        uint32_t neg = 0;
-        if (kind == 2) neg = (elem_byte<ES>(e, top_byte) & 0x80u) ? 0xFFu : 0u;
-        for (uint32_t k = 0; k < nd; ++k) {
-            const uint32_t b = key_offset + d0 + k;
-            uint32_t d = elem_byte<ES>(e, b);
-            const uint32_t flip = (b == top_byte && kind != 0) ? 0x80u : 0u;
-            d ^= (kind == 2 && neg) ? 0xFFu : flip;
-            atomicAdd(&lh[k * RADIX + d], 1u);
+    const uint32_t r = blockIdx.x / blocks_per_region;
+    const uint32_t sub = blockIdx.x % blocks_per_region;
+    const uint64_t begin = (uint64_t)r << g.region_shift;
+    uint64_t end = begin + (1ull << g.region_shift);
+    if (end > g.n) end = g.n;
+    const uint64_t stride = (uint64_t)blocks_per_region * blockDim.x;
+    for (uint64_t i = begin + (uint64_t)sub * blockDim.x + tid; i < end; i += stride) {
+        const uint32_t d = elem_digit<ES, FLT>(src[i], spec);
+        // skewed inputs put whole waves on one bin: count the wave with one atomic then
+        const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+        const uint64_t same = __ballot(d == d0);
+        if (same == __builtin_amdgcn_read_exec()) {
+            if (mbcnt64(same) == 0) atomicAdd(&lh[d0], (uint32_t)__popcll(same));
+        } else {
+            atomicAdd(&lh[d], 1u);
         }
     }
     __syncthreads();
-    for (uint32_t i = tid; i < nd * RADIX; i += blockDim.x) {
-        const uint32_t c = lh[i];
-        if (c) atomicAdd((unsigned long long*)&ghist[i], (unsigned long long)c);
+    if (tid < RADIX) {
+        const uint32_t c = lh[tid];
+        if (c) atomicAdd(&J[r * RADIX + tid], (unsigned long long)c);
     }
 }
 
-// In-place exclusive scan of each 256-bin row; optionally keeps the raw counts
-// in `counts_out` (same layout).  One workgroup (256 threads) per row.
-__global__ __launch_bounds__(256) void rsx_scan_kernel(uint64_t* __restrict__ ghist,
-                                                       uint64_t* __restrict__ counts_out) {
+// Prefix phase (mod.rs:110-120): from J[r][v] to the write cursor of every (region,
+// digit): base[r][v] = sum_{v' < v} sum_r' J[r'][v'] + sum_{r' < r} J[r'][v] -- the
+// digit-major, region-minor exclusive running sum.  One block of 256 threads.
+// Also clears what the coming sweep accumulates into (next J, region tickets) and
+// optionally returns the 256 digit totals.
+__global__ __launch_bounds__(256) void rsx_prefix_kernel(const unsigned long long* __restrict__ J,
+                                                         uint32_t num_regions, uint64_t* __restrict__ base,
+                                                         unsigned long long* __restrict__ jnext,
+                                                         uint32_t* __restrict__ tickets,
+                                                         uint64_t* __restrict__ counts_out) {
     __shared__ uint64_t wsum[4];
     const uint32_t tid = threadIdx.x;
-    uint64_t* row = ghist + (uint64_t)blockIdx.x * RADIX;
-    const uint64_t c = row[tid];
-    if (counts_out) counts_out[(uint64_t)blockIdx.x * RADIX + tid] = c;
+    uint64_t c = 0;
+    for (uint32_t r = 0; r < num_regions; ++r) c += J[r * RADIX + tid];
+    if (counts_out) counts_out[tid] = c;
     uint64_t x = c;
     const uint32_t lane = tid & 63;
 #pragma unroll
@@ -175,15 +204,22 @@ __global__ __launch_bounds__(256) void rsx_scan_kernel(uint64_t* __restrict__ gh
     }
     if (lane == 63) wsum[tid >> 6] = x;
     __syncthreads();
-    uint64_t base = 0;
-    for (uint32_t w = 0; w < (tid >> 6); ++w) base += wsum[w];
-    row[tid] = base + x - c;
+    uint64_t run = x - c;
+    for (uint32_t w = 0; w < (tid >> 6); ++w) run += wsum[w];
+    for (uint32_t r = 0; r < num_regions; ++r) {
+        base[r * RADIX + tid] = run;
+        run += J[r * RADIX + tid];
+    }
+    if (jnext)
+        for (uint32_t r = 0; r < MAX_REGIONS; ++r) jnext[r * RADIX + tid] = 0;
+    if (tid < MAX_REGIONS) tickets[tid] = 0;
 }
 
-// ----------------------------------------------------------------- onesweep --
+// -------------------------------------------------------------------- sweep --
 // Tile status word: [flag:2][value:BITS-2]; flag 0 = not ready, 1 = tile
-// aggregate, 2 = inclusive prefix.  The word is its own flag (one relaxed
-// agent-scope store/load per hop; no fence needed for a self-contained word).
+// aggregate, 2 = inclusive prefix (relative to the tile's region).  The word is its
+// own flag (one relaxed agent-scope store/load per hop; a self-contained word needs
+// no fence).
 template <typename S>
 struct Status;
 template <>
@@ -196,201 +232,357 @@ struct Status<uint64_t> {
     static constexpr int SHIFT = 62;
     static constexpr uint64_t MASK = (1ull << 62) - 1;
 };
-template <typename S>
-__device__ __forceinline__ uint64_t status_index(uint64_t tile, uint32_t digit) {
-    return tile * RADIX + digit;
-}
 
 struct SweepArgs {
     const void* src;
     void* dst;
-    uint64_t n;
-    const uint64_t* digit_start;  // [256] exclusive global starts of this digit
-    void* status;                 // [ntiles][256] status words (zeroed)
-    uint32_t* ticket;             // tile ticket counter (zeroed)
+    RegionGeom g;
+    const uint64_t* region_base;  // [num_regions][256] write cursor (elements) at region start
+    void* status;                 // [num_regions << (region_shift - log2 TILE)][256], zeroed
+    uint32_t* tickets;            // [MAX_REGIONS] per-region tile counters, zeroed
+    unsigned long long* jnext;    // [MAX_REGIONS][256] next pass's count matrix (accumulated), or null
     uint32_t* error;              // set non-zero if a bounded spin gave up
-    DigitSpec spec;
+    DigitSpec spec;               // this pass's digit
+    DigitSpec next;               // next pass's digit (when jnext != null)
     uint32_t dbg;                 // timing-only ablation switches (0 in production)
+    uint32_t stagger;             // start delay step between the workgroups of one chain (x 512 cycles)
     unsigned long long* dbg_cnt;  // [8] diagnostic counters (dbg & 0x100)
 };
 
-// Tile = WG threads x KPT elements, held wave-striped: wave w owns the
-// contiguous segment [w*64*KPT, (w+1)*64*KPT) of the tile and element j of lane
-// l is segment[j*64 + l], so (wave, j, lane) order == input order and ranks
-// computed in that order are stable.
-template <int ES, int KPT, int WG, typename S, bool FLT>
-__global__ __launch_bounds__(WG, (KPT * (ES < 4 ? 4 : ES) > 64 ? 4 : 6)) void rsx_onesweep_kernel(const SweepArgs a) {
+// Persistent workgroups pull tiles region by region (rotating, so consecutive tiles of
+// one chain start far apart in time).  Tile = WG threads x KPT elements, held
+// wave-striped: wave w owns the contiguous segment [w*64*KPT, (w+1)*64*KPT) of the
+// tile and element j of lane l is segment[j*64 + l], so (wave, j, lane) order == input
+// order and ranks computed in that order are stable.
+//
+// Per tile: load -> digit + wave64 match -> rank (wave counters in LDS) -> per-digit tile
+// counts (publish aggregate) -> scan -> LDS reorder -> look-back in the region's chain ->
+// run writes.  The ticket of the NEXT tile is drawn mid-tile and its loads are issued
+// before the write-out, so HBM latency hides behind the look-back and the stores.
+#ifdef RSX_STAMPS  // diagnostic build only: per-phase cycle shares of wave 0 (never in production)
+#define RSX_STAMP(k)                                                   \
+    do {                                                               \
+        const unsigned long long _t = __builtin_amdgcn_s_memtime();    \
+        stamp_acc[k] += _t - stamp_prev;                               \
+        stamp_prev = _t;                                               \
+    } while (0)
+#else
+#define RSX_STAMP(k) do {} while (0)
+#endif
+#ifndef RSX_MINW
+#define RSX_MINW 6
+#endif
+#ifndef RSX_MATCH_ILP
+#define RSX_MATCH_ILP 2
+#endif
+
+// Makes the compiler forget what it knows about the element registers: digits derived from them
+// are then re-derived where needed (2 VALU) instead of being kept live across phases (1 VGPR each).
+template <int ES, int KPT>
+__device__ __forceinline__ void forget(Elem<ES> (&e)[KPT]) {
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        if constexpr (ES < 4) {
+            uint32_t t = e[j].w[0];
+            asm volatile("" : "+v"(t));
+            e[j].w[0] = (decltype(e[j].w[0]))t;
+        } else {
+#pragma unroll
+            for (int k = 0; k < ES / 4; ++k) asm volatile("" : "+v"(e[j].w[k]));
+        }
+    }
+}
+
+template <int ES, int KPT>
+__device__ __forceinline__ void load_tile(Elem<ES> (&e)[KPT], const Elem<ES>* __restrict__ tile_ptr, uint32_t seg,
+                                          uint32_t valid, bool full) {
+    if (full) {  // immediates fold into the loads
+        const Elem<ES>* p0 = tile_ptr + seg;
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) e[j] = p0[j * WAVE];
+    } else {
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            // guarded, not clamped: a clamped address would be if-converted into the full path and
+            // cost 2 VGPRs per load there; the partial tile is the last one of a region, so rare
+            const uint32_t p = seg + j * WAVE;
+            if (p < valid) e[j] = tile_ptr[p];
+            else e[j] = Elem<ES>{};
+        }
+    }
+}
+
+template <int ES, int KPT, int WG, typename S, bool FLT, bool NEXT>
+__global__ __launch_bounds__(WG, (KPT * (ES < 4 ? 4 : ES) > 64 ? 4 : RSX_MINW)) void rsx_sweep_kernel(const SweepArgs a) {
     constexpr int NWAVE = WG / WAVE;
     constexpr int TILE = WG * KPT;
+    constexpr int TILE_LOG = __builtin_ctz(TILE);
+    static_assert((TILE & (TILE - 1)) == 0, "tile size must be a power of two (regions are whole tiles)");
     static_assert(WG >= RADIX, "need one thread per digit");
-    static_assert(TILE < (1 << 24), "rank must fit 24 bits");
+    static_assert(TILE <= 65536 / 2, "wave counters are 16 bit");
     using E = Elem<ES>;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    E* s_elems = reinterpret_cast<E*>(smem);                                          // [TILE]
-    uint64_t* s_base = reinterpret_cast<uint64_t*>(smem + (size_t)TILE * sizeof(E));  // [256] byte addresses
-    uint32_t* s_whist = reinterpret_cast<uint32_t*>(s_base + RADIX);                  // [NWAVE][256]
-    uint32_t* s_misc = s_whist + NWAVE * RADIX;                                       // [8]
+    E* s_elems = reinterpret_cast<E*>(smem);                                           // [TILE]
+    uint32_t* s_whist2 = reinterpret_cast<uint32_t*>(smem + (size_t)TILE * sizeof(E)); // [NWAVE][128]: 2 x 16-bit counters per word
+    uint16_t* s_whist = reinterpret_cast<uint16_t*>(s_whist2);                         // [NWAVE][256] same memory
+    uint64_t* s_base = reinterpret_cast<uint64_t*>(s_whist2);                          // [256], aliases s_whist (dead by then)
+    uint32_t* s_jn = s_whist2 + NWAVE * (RADIX / 2);                                   // [MAX_REGIONS][256] (NEXT)
+    uint32_t* s_misc = s_jn + (NEXT ? MAX_REGIONS * RADIX : 0);                        // [16]
+    static_assert(NWAVE * RADIX * sizeof(uint16_t) >= RADIX * sizeof(uint64_t), "s_base must fit in s_whist");
 
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63;
-    const uint32_t wave = tid >> 6;
     const E* __restrict__ src = static_cast<const E*>(a.src);
     S* status = static_cast<S*>(a.status);
+    const uint32_t NR = a.g.num_regions;
+    const uint32_t tpr_log = a.g.region_shift - TILE_LOG;  // log2(tiles per region)
+    const uint64_t region_len = 1ull << a.g.region_shift;
 
-    // ticket: tiles are handed out in start order, so every lower tile is already running
-    if (tid == 0) s_misc[0] = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t* my_hist = s_whist + wave * RADIX;
-#pragma unroll
-    for (int i = 0; i < RADIX / WAVE; ++i) my_hist[i * WAVE + lane] = 0;
-    __syncthreads();
-    const uint64_t tile = s_misc[0];
-    const uint64_t tile_base = tile * (uint64_t)TILE;
-    const uint64_t remain = a.n - tile_base;
-    const bool full = remain >= (uint64_t)TILE;
-    const uint32_t valid = full ? (uint32_t)TILE : (uint32_t)remain;
-    const uint32_t pad = TILE - valid;  // invalid tail slots, ranked as digit 255 after all valid ones
+    if (NEXT)
+        for (uint32_t i = threadIdx.x; i < MAX_REGIONS * RADIX; i += WG) s_jn[i] = 0;
 
-    // ---- load (wave-striped) + digit + match: all independent -> ILP ------------
-    E e[KPT];
-    uint32_t info[KPT];  // digit | below << 8 | count << 16, later digit | rank << 8
-    const uint32_t seg = wave * (WAVE * KPT) + lane;
-    if (full) {  // whole phase duplicated per branch: no pointer phis, immediates fold into the loads
-        const E* p0 = src + tile_base + seg;
-#pragma unroll
-        for (int j = 0; j < KPT; ++j) e[j] = p0[j * WAVE];
-#pragma unroll
-        for (int j = 0; j < KPT; ++j) {
-            const uint32_t d = elem_digit<ES, FLT>(e[j], a.spec);
-            const uint64_t m = (a.dbg & 8u) ? (uint64_t)d : match_digit(d);
-            info[j] = d | (mbcnt64(m) << 8) | ((uint32_t)__popcll(m) << 16);
-            // two matches in flight hide the SGPR-write -> VALU-read wait states; more only costs VGPRs
-            if (j % 2 == 1) __builtin_amdgcn_sched_barrier(0);
-        }
-    } else {
-        const E* p0 = src + tile_base;
-#pragma unroll
-        for (int j = 0; j < KPT; ++j) {
-            const uint32_t p = seg + j * WAVE;
-            e[j] = p0[p < valid ? p : valid - 1];  // clamped: always in bounds
-        }
-#pragma unroll
-        for (int j = 0; j < KPT; ++j) {
-            uint32_t d = elem_digit<ES, FLT>(e[j], a.spec);
-            if (seg + j * WAVE >= valid) d = 255u;
-            const uint64_t m = match_digit(d);
-            info[j] = d | (mbcnt64(m) << 8) | ((uint32_t)__popcll(m) << 16);
-            if (j % 2 == 1) __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-
-    // ---- rank within the wave (stable): serial over rounds through the wave's LDS counters
-    if (!(a.dbg & 4u))
-#pragma unroll
-    for (int j = 0; j < KPT; ++j) {
-        const uint32_t d = info[j] & 0xFFu;
-        const uint32_t below = (info[j] >> 8) & 0xFFu;
-        const uint32_t prev = my_hist[d];
-        __builtin_amdgcn_wave_barrier();
-        if (below == 0) my_hist[d] = prev + (info[j] >> 16);
-        __builtin_amdgcn_wave_barrier();
-        info[j] = d | ((prev + below) << 8);
-    }
-    __syncthreads();
-
-    // ---- per-digit: wave counts -> tile count, publish aggregate --------------
-    uint32_t cw[NWAVE];
-    uint32_t tcount = 0;
-    if (tid < RADIX) {
-#pragma unroll
-        for (int w = 0; w < NWAVE; ++w) {
-            cw[w] = s_whist[w * RADIX + tid];
-            tcount += cw[w];
-        }
-        const uint32_t real = (tid == 255) ? tcount - pad : tcount;
-        const S flag = (tile == 0) ? (S)2 : (S)1;
-        __hip_atomic_store(&status[status_index<S>(tile, tid)], (flag << Status<S>::SHIFT) | (S)real, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // exclusive scan of tcount over the 256 digits -> start of each digit's run in the tile
-    uint32_t incl = tcount;
-    if (tid < RADIX) {
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t y = __shfl_up(incl, o);
-            if (lane >= (uint32_t)o) incl += y;
-        }
-        if (lane == 63) s_misc[1 + wave] = incl;
-    }
-    __syncthreads();
-    uint32_t tstart = 0;
-    if (tid < RADIX) {
-        uint32_t wbase = 0;
-        for (uint32_t w = 0; w < wave; ++w) wbase += s_misc[1 + w];
-        tstart = wbase + incl - tcount;
-        uint32_t run = tstart;
-#pragma unroll
-        for (int w = 0; w < NWAVE; ++w) {
-            s_whist[w * RADIX + tid] = run;
-            run += cw[w];
-        }
-    }
-    __syncthreads();
-
-    // ---- reorder the tile in LDS by digit -------------------------------------
-#pragma unroll
-    for (int j = 0; j < KPT; ++j) s_elems[my_hist[info[j] & 0xFFu] + (info[j] >> 8)] = e[j];
-
-    // ---- decoupled look-back: exclusive count of my digit over lower tiles ----
-    if (tid < RADIX) {
-        uint64_t excl = 0;
-        if (tile > 0 && !(a.dbg & 1u)) {
-            uint64_t p = tile - 1;
-            uint32_t spins = 0, hops = 0;
-            while (true) {
-                ++hops;
-                const S s = __hip_atomic_load(&status[status_index<S>(p, tid)], __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t f = (uint32_t)(s >> Status<S>::SHIFT);
-                if (f == 0) {
-                    if (++spins > (1u << 22)) {  // bounded: never hang the device
-                        atomicExch(a.error, 1u);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                    continue;
-                }
-                excl += (uint64_t)(s & Status<S>::MASK);
-                if (f == 2) break;
-                --p;
+    // ---- tile tickets (thread 0) ----------------------------------------------------
+    // tiles of region r are handed out in order by tickets[r], so every lower tile of a
+    // chain is already running when a tile starts; a workgroup walks the regions round-robin.
+    uint32_t rr = blockIdx.x % NR;  // region the next ticket is drawn from
+    uint32_t alive = NR;            // regions not yet seen exhausted
+    uint32_t exhausted = 0;         // bitmask of exhausted regions
+    // resolve ticket `k` of region `r` into a tile, drawing further tickets while regions run dry
+    auto resolve = [&](uint32_t r, uint32_t k, uint32_t slot) {
+        bool have = false;
+        while (alive > 0) {
+            const uint64_t rbeg = (uint64_t)r << a.g.region_shift;
+            const uint64_t rlen = (a.g.n - rbeg) < region_len ? (a.g.n - rbeg) : region_len;
+            const uint32_t nt = (uint32_t)((rlen + TILE - 1) >> TILE_LOG);
+            if (k < nt) {
+                have = true;
+                break;
             }
-            if ((a.dbg & 0x100u) && tid == 0) {  // diagnostics: hop / stall statistics of digit 0
-                atomicAdd(&a.dbg_cnt[0], 1ull);
-                atomicAdd(&a.dbg_cnt[1], (unsigned long long)hops);
-                atomicAdd(&a.dbg_cnt[2], (unsigned long long)spins);
-                atomicAdd(&a.dbg_cnt[3], (unsigned long long)(tile - p));
-                atomicMax(&a.dbg_cnt[4], (unsigned long long)hops);
+            if (!(exhausted >> r & 1u)) {
+                exhausted |= 1u << r;
+                --alive;
             }
+            if (alive == 0) break;
+            do r = (r + 1 == NR) ? 0 : r + 1;
+            while (exhausted >> r & 1u);
+            k = __hip_atomic_fetch_add(&a.tickets[r], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_misc[slot + 0] = have ? 1u : 0u;
+        s_misc[slot + 1] = r;
+        s_misc[slot + 2] = k;
+        if (have) rr = r;  // stay on this chain until it runs dry
+    };
+    // workgroups of one chain start spread over about one tile time, so that the tiles of a
+    // chain are processed evenly spaced instead of in bunches (a bunch looks back through itself)
+    if (threadIdx.x == 0)
+        for (uint32_t i = 0, n = (blockIdx.x / NR) * a.stagger; i < n; ++i) __builtin_amdgcn_s_sleep(8);
+
+#ifdef RSX_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+#endif
+    while (true) {
+        // thread coordinates are re-derived per tile from an opaque copy of threadIdx: otherwise
+        // every tid-derived address (dozens of VGPRs) is hoisted out of this loop and spilled
+        uint32_t tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const uint32_t lane = tid & 63;
+        const uint32_t wave = tid >> 6;
+        uint32_t* my_hist2 = s_whist2 + wave * (RADIX / 2);
+        uint16_t* my_hist = s_whist + wave * RADIX;
+        reinterpret_cast<uint64_t*>(my_hist2)[lane] = 0;  // each wave clears its 256 16-bit counters
+        // ticket drawn when the tile starts: ticket order == start order inside a chain
+        if (tid == 0)
+            resolve(rr, __hip_atomic_fetch_add(&a.tickets[rr], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0);
+        __syncthreads();
+        RSX_STAMP(0);
+        if (s_misc[0] == 0) break;
+        const uint32_t reg = s_misc[1];
+        const uint32_t kt = s_misc[2];
+
+        const uint64_t tile_base = ((uint64_t)reg << a.g.region_shift) + ((uint64_t)kt << TILE_LOG);
+        const uint64_t rend = ((uint64_t)(reg + 1) << a.g.region_shift) < a.g.n ? ((uint64_t)(reg + 1) << a.g.region_shift) : a.g.n;
+        const uint64_t remain = rend - tile_base;
+        const bool full = remain >= (uint64_t)TILE;
+        const uint32_t valid = full ? (uint32_t)TILE : (uint32_t)remain;
+        const uint32_t pad = TILE - valid;  // invalid tail slots, ranked as digit 255 after all valid ones
+        const uint64_t stat_row = (((uint64_t)reg << tpr_log) + kt) * RADIX;
+        const uint32_t seg = wave * (WAVE * KPT) + lane;
+
+        // ---- load + digit + match: independent -> ILP ------------
+        E e[KPT];
+        load_tile<ES, KPT>(e, src + tile_base, seg, valid, full);
+        // per element 16 bits of bookkeeping, two elements per VGPR: first
+        // (lanes below me with my digit) | (size of my digit group - 1) << 6, later the tile rank.
+        // The digit itself is re-derived from the element when needed (2 VALU) instead of kept.
+        uint32_t pk[(KPT + 1) / 2];
+#pragma unroll
+        for (int j = 0; j < (KPT + 1) / 2; ++j) pk[j] = 0;
+        if (full) {  // branch-free body (the common case)
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                const uint64_t m = match_digit(elem_digit<ES, FLT>(e[j], a.spec));
+                pk[j / 2] |= (mbcnt64(m) | (((uint32_t)__popcll(m) - 1u) << 6)) << (16 * (j & 1));
+                // two matches in flight hide the SGPR-write -> VALU-read wait states; more only costs VGPRs
+                if (j % RSX_MATCH_ILP == RSX_MATCH_ILP - 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                const uint32_t d = (seg + j * WAVE >= valid) ? 255u : elem_digit<ES, FLT>(e[j], a.spec);
+                const uint64_t m = match_digit(d);
+                pk[j / 2] |= (mbcnt64(m) | (((uint32_t)__popcll(m) - 1u) << 6)) << (16 * (j & 1));
+                if (j % RSX_MATCH_ILP == RSX_MATCH_ILP - 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        RSX_STAMP(1);
+
+        forget<ES, KPT>(e);
+        // ---- rank within the wave (stable).  Per round: every lane reads its digit's running
+        // count, then the first lane of each digit group adds the group size -- an atomic add, so
+        // nothing waits on the read: all 2*KPT LDS ops pipeline (LDS serves a wave in order).
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t d = (!full && seg + j * WAVE >= valid) ? 255u : elem_digit<ES, FLT>(e[j], a.spec);
+            const uint32_t v = (pk[j / 2] >> (16 * (j & 1))) & 0xFFFFu;
+            const uint32_t below = v & 63u;
+            const uint32_t sh = (d & 1u) * 16u;  // two 16-bit counters per LDS word
+            const uint32_t prev = (my_hist2[d >> 1] >> sh) & 0xFFFFu;
+            if (below == 0) atomicAdd(&my_hist2[d >> 1], ((v >> 6) + 1u) << sh);
+            const uint32_t rank = prev + below;
+            pk[j / 2] = (j & 1) ? ((pk[j / 2] & 0xFFFFu) | (rank << 16)) : ((pk[j / 2] & 0xFFFF0000u) | rank);
+            if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        RSX_STAMP(2);
+
+        // ---- per-digit: wave counts -> tile count, publish aggregate --------------
+        uint32_t tcount = 0;
+        if (tid < RADIX) {
+#pragma unroll
+            for (int w = 0; w < NWAVE; ++w) tcount += s_whist[w * RADIX + tid];
             const uint32_t real = (tid == 255) ? tcount - pad : tcount;
-            __hip_atomic_store(&status[status_index<S>(tile, tid)],
-                               ((S)2 << Status<S>::SHIFT) | (S)((excl + real) & (uint64_t)Status<S>::MASK),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const S flag = (kt == 0) ? (S)2 : (S)1;  // first tile of a chain: aggregate == inclusive
+            __hip_atomic_store(&status[stat_row + tid], (flag << Status<S>::SHIFT) | (S)real, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         }
-        // byte address of LDS slot 0 if it belonged to this digit's run (wrap-safe in u64)
-        s_base[tid] = reinterpret_cast<uint64_t>(a.dst) + (a.digit_start[tid] + excl - (uint64_t)tstart) * ES;
-    }
-    __syncthreads();
-
-    // ---- write runs: consecutive threads -> consecutive addresses within a run -
-    if (!(a.dbg & 2u)) {
+        // exclusive scan of tcount over the 256 digits -> start of each digit's run in the tile
+        uint32_t incl = tcount;
+        if (tid < RADIX) {
 #pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            const uint32_t p = i * WG + tid;
-            if (full || p < valid) {
-                const E x = s_elems[p];
-                const uint32_t d = elem_digit<ES, FLT>(x, a.spec);
-                *reinterpret_cast<E*>(s_base[d] + (uint64_t)p * ES) = x;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t y = __shfl_up(incl, o);
+                if (lane >= (uint32_t)o) incl += y;
             }
+            if (lane == 63) s_misc[12 + wave] = incl;
+        }
+        __syncthreads();
+        uint32_t tstart = 0;
+        if (tid < RADIX) {
+            uint32_t wbase = 0;
+            for (uint32_t w = 0; w < wave; ++w) wbase += s_misc[12 + w];
+            tstart = wbase + incl - tcount;
+            uint32_t run = tstart;
+#pragma unroll
+            for (int w = 0; w < NWAVE; ++w) {  // counts are re-read rather than kept in 8 VGPRs across the barrier
+                const uint32_t c = s_whist[w * RADIX + tid];
+                s_whist[w * RADIX + tid] = (uint16_t)run;
+                run += c;
+            }
+        }
+        __syncthreads();
+        RSX_STAMP(3);
+
+        // ---- reorder the tile in LDS by digit -------------------------------------
+        forget<ES, KPT>(e);
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const uint32_t d = (!full && seg + j * WAVE >= valid) ? 255u : elem_digit<ES, FLT>(e[j], a.spec);
+            s_elems[my_hist[d] + ((pk[j / 2] >> (16 * (j & 1))) & 0xFFFFu)] = e[j];
+        }
+        __syncthreads();  // s_whist is dead from here: s_base takes its place
+        RSX_STAMP(4);
+
+        // ---- decoupled look-back inside the region's chain -----------------------
+        if (tid < RADIX) {
+            uint64_t excl = 0;
+            if (kt > 0 && !(a.dbg & 1u)) {
+                uint64_t row = stat_row - RADIX;  // predecessor in the chain
+                uint32_t spins = 0, hops = 0;
+                while (true) {
+                    ++hops;
+                    const S s = __hip_atomic_load(&status[row + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t f = (uint32_t)(s >> Status<S>::SHIFT);
+                    if (f == 0) {
+                        if (++spins > (1u << 22)) {  // bounded: never hang the device
+                            atomicExch(a.error, 1u);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                        continue;
+                    }
+                    excl += (uint64_t)(s & Status<S>::MASK);
+                    if (f == 2) break;
+                    row -= RADIX;
+                }
+                if ((a.dbg & 0x100u) && tid == 0) {  // diagnostics: hop / stall statistics of digit 0
+                    atomicAdd(&a.dbg_cnt[0], 1ull);
+                    atomicAdd(&a.dbg_cnt[1], (unsigned long long)hops);
+                    atomicAdd(&a.dbg_cnt[2], (unsigned long long)spins);
+                    atomicMax(&a.dbg_cnt[4], (unsigned long long)hops);
+                }
+                const uint32_t real = (tid == 255) ? tcount - pad : tcount;
+                __hip_atomic_store(&status[stat_row + tid],
+                                   ((S)2 << Status<S>::SHIFT) | (S)((excl + real) & (uint64_t)Status<S>::MASK),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // element index of LDS slot 0 if it belonged to this digit's run (wrap-safe in u64)
+            s_base[tid] = a.region_base[reg * RADIX + tid] + excl - (uint64_t)tstart;
+        }
+        __syncthreads();
+        RSX_STAMP(5);
+
+        // ---- write runs: consecutive threads -> consecutive addresses within a run;
+        // ---- count the NEXT pass's digit per destination region on the way out
+        if (!(a.dbg & 2u)) {
+            E* __restrict__ dst = static_cast<E*>(a.dst);
+            if (full) {
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) {
+                    const uint32_t p = i * WG + tid;
+                    const E x = s_elems[p];
+                    const uint64_t idx = s_base[elem_digit<ES, FLT>(x, a.spec)] + p;
+                    dst[idx] = x;
+                    if (NEXT && !(a.dbg & 16u))
+                        atomicAdd(&s_jn[((uint32_t)(idx >> a.g.region_shift) << 8) | elem_digit<ES, FLT>(x, a.next)], 1u);
+                    // bound the look-ahead: x + 64-bit base per element in flight is 3 VGPRs each
+                    if (i % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < KPT; ++i) {
+                    const uint32_t p = i * WG + tid;
+                    if (p < valid) {
+                        const E x = s_elems[p];
+                        const uint64_t idx = s_base[elem_digit<ES, FLT>(x, a.spec)] + p;
+                        dst[idx] = x;
+                        if (NEXT)
+                            atomicAdd(&s_jn[((uint32_t)(idx >> a.g.region_shift) << 8) | elem_digit<ES, FLT>(x, a.next)], 1u);
+                    }
+                }
+            }
+        }
+        __syncthreads();  // s_elems / s_base are reused by the next tile
+        RSX_STAMP(6);
+    }
+#ifdef RSX_STAMPS
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 7; ++k) atomicAdd(&a.dbg_cnt[k], stamp_acc[k]);
+#endif
+
+    if (NEXT) {  // hand this workgroup's share of the next count matrix over
+        for (uint32_t i = threadIdx.x; i < MAX_REGIONS * RADIX; i += WG) {
+            const uint32_t c = s_jn[i];
+            if (c) atomicAdd(&a.jnext[i], (unsigned long long)c);
         }
     }
 }

@@ -43,7 +43,7 @@ def test_code_object_is_gfx950():
     from radix_sort_amd import _build
     blob = open(_build.LIB, "rb").read()
     assert b"gfx950" in blob
-    assert b"rsx_onesweep_kernel" in blob and b"rsx_hist_kernel" in blob
+    assert b"rsx_sweep_kernel" in blob and b"rsx_hist_kernel" in blob
 
 
 def test_layout_struct_matches_header():
