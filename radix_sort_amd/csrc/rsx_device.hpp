@@ -108,8 +108,12 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {  // set bits of m belo
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// Lanes of the wave whose 8-bit digit equals mine ("match any" on wave64):
-// 8 ballots, one per digit bit.
+// Lanes of the wave whose 8-bit digit equals mine ("match any" on wave64): per digit bit
+// one sign-extension of the bit (v_bfe_i32), one ballot (v_cmp -> SGPR pair) and one v_bitop3
+// per mask half: m &= ~(ballot ^ mybit) (LUT 0x90) -- 32 VALU per key plus the wait states
+// hipcc pads between a VALU writing an SGPR and a VALU reading it.  (A hand-scheduled asm block
+// with 8 distinct SGPR pairs removes the pads but costs 4-8 more live VGPRs: measured no faster,
+// the kernel is latency-bound, not issue-bound.)
 __device__ __forceinline__ uint64_t match_digit(uint32_t d) {
     uint32_t lo = ~0u, hi = ~0u;
 #pragma unroll
@@ -117,7 +121,6 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d) {
         uint32_t ext = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);  // bit b replicated to 32 bits
         asm volatile("" : "+v"(ext));  // keep the compare on `ext` (else it is re-derived from d: +1 VALU)
         const uint64_t bal = __builtin_amdgcn_ballot_w64(ext != 0);
-        // m &= ~(ballot ^ mybit): lanes whose bit b equals mine; one v_bitop3 per half (LUT 0x90)
         lo = __builtin_amdgcn_bitop3_b32(lo, (uint32_t)bal, ext, 0x90);
         hi = __builtin_amdgcn_bitop3_b32(hi, (uint32_t)(bal >> 32), ext, 0x90);
     }
@@ -369,13 +372,8 @@ __global__ __launch_bounds__(WG, (KPT * (ES < 4 ? 4 : ES) > 64 ? 4 : RSX_MINW)) 
         s_misc[slot + 0] = have ? 1u : 0u;
         s_misc[slot + 1] = r;
         s_misc[slot + 2] = k;
-        if (have) rr = r;  // stay on this chain until it runs dry
+        if (have) rr = r;  // stay on this chain until it runs dry (rotating chains bunch up: measured slower)
     };
-    // workgroups of one chain start spread over about one tile time, so that the tiles of a
-    // chain are processed evenly spaced instead of in bunches (a bunch looks back through itself)
-    if (threadIdx.x == 0)
-        for (uint32_t i = 0, n = (blockIdx.x / NR) * a.stagger; i < n; ++i) __builtin_amdgcn_s_sleep(8);
-
 #ifdef RSX_STAMPS
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
@@ -390,7 +388,9 @@ __global__ __launch_bounds__(WG, (KPT * (ES < 4 ? 4 : ES) > 64 ? 4 : RSX_MINW)) 
         uint32_t* my_hist2 = s_whist2 + wave * (RADIX / 2);
         uint16_t* my_hist = s_whist + wave * RADIX;
         reinterpret_cast<uint64_t*>(my_hist2)[lane] = 0;  // each wave clears its 256 16-bit counters
-        // ticket drawn when the tile starts: ticket order == start order inside a chain
+        // The ticket is drawn when the tile starts, so ticket order == start order inside a chain.
+        // (Drawing it earlier hides the atomic's round trip but makes a workgroup sit on a ticket
+        // while the tiles behind it in the chain already wait for its aggregate: measured slower.)
         if (tid == 0)
             resolve(rr, __hip_atomic_fetch_add(&a.tickets[rr], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0);
         __syncthreads();
