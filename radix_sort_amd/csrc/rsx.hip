@@ -29,7 +29,6 @@ constexpr size_t OFF_TICKETS = OFF_BASE + J_BYTES;  // [MAX_REGIONS] u32
 constexpr size_t OFF_ERROR = OFF_TICKETS + 64;
 constexpr size_t OFF_DBG = OFF_ERROR + 64;  // 8 diagnostic counters
 constexpr size_t AUX_BYTES = OFF_DBG + 64;
-constexpr int SWEEP_WG = 512;
 }  // namespace
 
 struct rsx_ctx {
@@ -123,8 +122,18 @@ bool aligned(const void* p, uint32_t a) { return (reinterpret_cast<uintptr_t>(p)
 #ifndef RSX_KPT4
 #define RSX_KPT4 16
 #endif
-constexpr int kpt_for(int es) { return es <= 4 ? RSX_KPT4 : es == 8 ? 8 : es <= 16 ? 4 : 2; }
-constexpr uint32_t tile_elems(int es) { return SWEEP_WG * kpt_for(es); }
+#ifndef RSX_WG4
+#define RSX_WG4 512
+#endif
+#ifndef RSX_KPT8
+#define RSX_KPT8 8
+#endif
+#ifndef RSX_WG8
+#define RSX_WG8 512
+#endif
+constexpr int kpt_for(int es) { return es <= 4 ? RSX_KPT4 : es == 8 ? RSX_KPT8 : es <= 16 ? 4 : 2; }
+constexpr int wg_for(int es) { return es <= 4 ? RSX_WG4 : es == 8 ? RSX_WG8 : 512; }
+constexpr uint32_t tile_elems(int es) { return wg_for(es) * kpt_for(es); }
 
 uint32_t log2u(uint64_t x) { return 63u - (uint32_t)__builtin_clzll(x); }
 
@@ -133,7 +142,12 @@ RegionGeom make_geom(uint64_t n, uint32_t es) {
     RegionGeom g;
     g.n = n;
     uint32_t k = log2u(tile_elems((int)es));
-    while (((n + (1ull << k) - 1) >> k) > (uint64_t)MAX_REGIONS) ++k;
+    static const uint64_t max_regions = [] {  // RSX_REGIONS env: tuning/diagnostics only
+        const char* e = std::getenv("RSX_REGIONS");
+        const uint64_t v = e ? std::strtoull(e, nullptr, 0) : 0;
+        return (v >= 1 && v <= (uint64_t)MAX_REGIONS) ? v : (uint64_t)MAX_REGIONS;
+    }();
+    while (((n + (1ull << k) - 1) >> k) > max_regions) ++k;
     g.region_shift = k;
     g.num_regions = (uint32_t)((n + (1ull << k) - 1) >> k);
     if (g.num_regions == 0) g.num_regions = 1;
@@ -235,6 +249,7 @@ template <int ES, typename S, bool FLT, bool NEXT>
 int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L,
                    uint32_t digit, unsigned long long* jnext, hipStream_t st) {
     constexpr int KPT = kpt_for(ES);
+    constexpr int SWEEP_WG = wg_for(ES);
     constexpr int TILE = SWEEP_WG * KPT;
     const uint64_t rows = status_rows(g, ES);
     RSX_HIP(hipMemsetAsync(ctx->status, 0, (size_t)rows * RADIX * sizeof(S), st));

@@ -161,12 +161,11 @@ __global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restric
     __syncthreads();
     const uint32_t r = blockIdx.x / blocks_per_region;
     const uint32_t sub = blockIdx.x % blocks_per_region;
-    const uint64_t begin = (uint64_t)r << g.region_shift;
+    const uint64_t begin = (uint64_t)r << g.region_shift;  // a multiple of the tile size: 16-byte aligned
     uint64_t end = begin + (1ull << g.region_shift);
     if (end > g.n) end = g.n;
-    const uint64_t stride = (uint64_t)blocks_per_region * blockDim.x;
-    for (uint64_t i = begin + (uint64_t)sub * blockDim.x + tid; i < end; i += stride) {
-        const uint32_t d = elem_digit<ES, FLT>(src[i], spec);
+    auto count = [&](const Elem<ES>& e) {
+        const uint32_t d = elem_digit<ES, FLT>(e, spec);
         // skewed inputs put whole waves on one bin: count the wave with one atomic then
         const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
         const uint64_t same = __ballot(d == d0);
@@ -175,6 +174,23 @@ __global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restric
         } else {
             atomicAdd(&lh[d], 1u);
         }
+    };
+    // order inside a region does not matter for a count: 16-byte loads
+    constexpr int VEC = (ES == 1 || ES == 2 || ES == 4 || ES == 8) ? 16 / ES : 1;
+    struct alignas(VEC > 1 ? 16 : alignof(Elem<ES>)) Pack {
+        Elem<ES> e[VEC];
+    };
+    const uint64_t nvec = (end - begin) / VEC;
+    const Pack* vsrc = reinterpret_cast<const Pack*>(src + begin);
+    const uint64_t stride = (uint64_t)blocks_per_region * blockDim.x;
+    for (uint64_t i = (uint64_t)sub * blockDim.x + tid; i < nvec; i += stride) {
+        const Pack p = vsrc[i];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) count(p.e[k]);
+    }
+    if (VEC > 1 && sub == 0) {  // tail of the region (fewer than VEC elements)
+        const uint64_t i = begin + nvec * VEC + tid;
+        if (i < end) count(src[i]);
     }
     __syncthreads();
     if (tid < RADIX) {
@@ -316,7 +332,7 @@ __device__ __forceinline__ void load_tile(Elem<ES> (&e)[KPT], const Elem<ES>* __
 }
 
 template <int ES, int KPT, int WG, typename S, bool FLT, bool NEXT>
-__global__ __launch_bounds__(WG, (KPT * (ES < 4 ? 4 : ES) > 64 ? 4 : RSX_MINW)) void rsx_sweep_kernel(const SweepArgs a) {
+__global__ __launch_bounds__(WG, (WG == 1024 ? 8 : KPT * (ES < 4 ? 4 : ES) > 64 ? 4 : RSX_MINW)) void rsx_sweep_kernel(const SweepArgs a) {
     constexpr int NWAVE = WG / WAVE;
     constexpr int TILE = WG * KPT;
     constexpr int TILE_LOG = __builtin_ctz(TILE);
@@ -346,7 +362,12 @@ __global__ __launch_bounds__(WG, (KPT * (ES < 4 ? 4 : ES) > 64 ? 4 : RSX_MINW)) 
     // ---- tile tickets (thread 0) ----------------------------------------------------
     // tiles of region r are handed out in order by tickets[r], so every lower tile of a
     // chain is already running when a tile starts; a workgroup walks the regions round-robin.
-    uint32_t rr = blockIdx.x % NR;  // region the next ticket is drawn from
+    uint32_t rr = (a.dbg & 0x800u) ? (blockIdx.x * NR / gridDim.x) % NR : blockIdx.x % NR;  // region the next ticket is drawn from
+    // Regions are a power of two apart, so chains that advance in lockstep hit the same HBM
+    // banks (different rows) at the same time; chain r therefore starts r * stagger * 512 cycles
+    // late and stays that many tiles behind its neighbours for the whole pass.
+    if (threadIdx.x == 0)
+        for (uint32_t i = 0, n = rr * a.stagger; i < n; ++i) __builtin_amdgcn_s_sleep(8);
     uint32_t alive = NR;            // regions not yet seen exhausted
     uint32_t exhausted = 0;         // bitmask of exhausted regions
     // resolve ticket `k` of region `r` into a tile, drawing further tickets while regions run dry
@@ -409,6 +430,7 @@ __global__ __launch_bounds__(WG, (KPT * (ES < 4 ? 4 : ES) > 64 ? 4 : RSX_MINW)) 
         const uint32_t seg = wave * (WAVE * KPT) + lane;
 
         // ---- load + digit + match: independent -> ILP ------------
+        __builtin_amdgcn_s_setprio(0);
         E e[KPT];
         load_tile<ES, KPT>(e, src + tile_base, seg, valid, full);
         // per element 16 bits of bookkeeping, two elements per VGPR: first
@@ -454,6 +476,9 @@ __global__ __launch_bounds__(WG, (KPT * (ES < 4 ? 4 : ES) > 64 ? 4 : RSX_MINW)) 
         }
         __syncthreads();
         RSX_STAMP(2);
+        // from here to the end of the tile the workgroup is on short, serial phases that every
+        // wave waits for: let them win issue arbitration over other workgroups' match phases
+        if (!(a.dbg & 0x1000u)) __builtin_amdgcn_s_setprio(2);
 
         // ---- per-digit: wave counts -> tile count, publish aggregate --------------
         uint32_t tcount = 0;
@@ -506,6 +531,8 @@ __global__ __launch_bounds__(WG, (KPT * (ES < 4 ? 4 : ES) > 64 ? 4 : RSX_MINW)) 
         if (tid < RADIX) {
             uint64_t excl = 0;
             if (kt > 0 && !(a.dbg & 1u)) {
+                // one predecessor per hop: examining several per round trip was measured slower
+                // (the extra status reads cost more than the saved latency)
                 uint64_t row = stat_row - RADIX;  // predecessor in the chain
                 uint32_t spins = 0, hops = 0;
                 while (true) {
