@@ -114,10 +114,11 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {  // set bits of m belo
 // hipcc pads between a VALU writing an SGPR and a VALU reading it.  (A hand-scheduled asm block
 // with 8 distinct SGPR pairs removes the pads but costs 4-8 more live VGPRs: measured no faster,
 // the kernel is latency-bound, not issue-bound.)
+template <int NB = 8>
 __device__ __forceinline__ uint64_t match_digit(uint32_t d) {
     uint32_t lo = ~0u, hi = ~0u;
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < NB; ++b) {
         uint32_t ext = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1);  // bit b replicated to 32 bits
         asm volatile("" : "+v"(ext));  // keep the compare on `ext` (else it is re-derived from d: +1 VALU)
         const uint64_t bal = __builtin_amdgcn_ballot_w64(ext != 0);
@@ -309,6 +310,21 @@ __device__ __forceinline__ void forget(Elem<ES> (&e)[KPT]) {
 #pragma unroll
             for (int k = 0; k < ES / 4; ++k) asm volatile("" : "+v"(e[j].w[k]));
         }
+    }
+}
+
+// One count into the next pass's count matrix (LDS).  Uniform keys: one LDS atomic per lane.
+// Skewed keys put many lanes of a wave on one bin, and same-address LDS atomics serialise; when
+// at least a quarter of the wave shares the first lane's bin the wave matches its bins instead
+// (12 bits: region | digit) and one lane per bin adds the group size.
+__device__ __forceinline__ void count_next(uint32_t* s_jn, uint32_t bin) {
+    const uint32_t b0 = __builtin_amdgcn_readfirstlane(bin);
+    const uint64_t same = __ballot(bin == b0);
+    if (__popcll(same) >= 16) {  // wave-uniform
+        const uint64_t m = match_digit<12>(bin) & __builtin_amdgcn_read_exec();
+        if (mbcnt64(m) == 0) atomicAdd(&s_jn[bin], (uint32_t)__popcll(m));
+    } else {
+        atomicAdd(&s_jn[bin], 1u);
     }
 }
 
@@ -580,7 +596,7 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : KPT * (ES < 4 ? 4 : ES) > 64 
                     const uint64_t idx = s_base[elem_digit<ES, FLT>(x, a.spec)] + p;
                     dst[idx] = x;
                     if (NEXT && !(a.dbg & 16u))
-                        atomicAdd(&s_jn[((uint32_t)(idx >> a.g.region_shift) << 8) | elem_digit<ES, FLT>(x, a.next)], 1u);
+                        count_next(s_jn, ((uint32_t)(idx >> a.g.region_shift) << 8) | elem_digit<ES, FLT>(x, a.next));
                     // bound the look-ahead: x + 64-bit base per element in flight is 3 VGPRs each
                     if (i % 4 == 3) __builtin_amdgcn_sched_barrier(0);
                 }
@@ -593,7 +609,7 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : KPT * (ES < 4 ? 4 : ES) > 64 
                         const uint64_t idx = s_base[elem_digit<ES, FLT>(x, a.spec)] + p;
                         dst[idx] = x;
                         if (NEXT)
-                            atomicAdd(&s_jn[((uint32_t)(idx >> a.g.region_shift) << 8) | elem_digit<ES, FLT>(x, a.next)], 1u);
+                            count_next(s_jn, ((uint32_t)(idx >> a.g.region_shift) << 8) | elem_digit<ES, FLT>(x, a.next));
                     }
                 }
             }
