@@ -111,6 +111,9 @@ class ShardedRadixSort:
         self.rank = dist.get_rank(group)
         self.backend = backend or HipBackend()
         self._bufs = {}
+        # gloo moves host memory only: device slices are staged through the host for the two
+        # collectives (test rigs: several ranks on one GPU).  RCCL ("nccl") runs device to device.
+        self.host_staged = dist.get_backend(group) == "gloo"
 
     def _buf(self, name: str, nbytes: int):
         b = self._bufs.get(name)
@@ -138,12 +141,24 @@ class ShardedRadixSort:
         gathered = [torch.zeros(256, dtype=torch.int64, device=x.device) for _ in range(self.world)]
         for digit in range(d.key_bytes):  # mod.rs:84
             be.partition(x, part, n_local, d, digit, hist)  # count + local stable scatter
-            dist.all_gather(gathered, hist, group=self.group)  # the G x 256 counts
-            H = torch.stack(gathered).cpu().numpy()
+            if self.host_staged and hist.is_cuda:
+                hcpu = hist.cpu()
+                gl = [torch.zeros(256, dtype=torch.int64) for _ in range(self.world)]
+                dist.all_gather(gl, hcpu, group=self.group)
+                H = torch.stack(gl).numpy()
+            else:
+                dist.all_gather(gathered, hist, group=self.group)  # the G x 256 counts
+                H = torch.stack(gathered).cpu().numpy()
             send_counts, recv_counts, segs = exchange_plan(H, n_per_rank, self.rank)
             assert send_counts.sum() == n_local and recv_counts.sum() == n_local
-            dist.all_to_all_single(recv, part, output_split_sizes=(recv_counts * es).tolist(),
-                                   input_split_sizes=(send_counts * es).tolist(), group=self.group)
+            if self.host_staged and part.is_cuda:
+                rc = torch.empty(n_local * es, dtype=torch.uint8)
+                dist.all_to_all_single(rc, part.cpu(), output_split_sizes=(recv_counts * es).tolist(),
+                                       input_split_sizes=(send_counts * es).tolist(), group=self.group)
+                recv.copy_(rc)
+            else:
+                dist.all_to_all_single(recv, part, output_split_sizes=(recv_counts * es).tolist(),
+                                       input_split_sizes=(send_counts * es).tolist(), group=self.group)
             nseg = segs.shape[0]
             if nseg:
                 so = be.to_device_i64(np.ascontiguousarray(segs[:, 0]))

@@ -1,0 +1,146 @@
+//! Drop-in for `jgrodzki/radix_sort`'s sort path: the two public traits of the reference
+//! (`src/radix_sort/mod.rs:18-20`, `src/radix_sort/radix_digits.rs:1-5`) with the body of
+//! `radix_sort()` replaced by one call into the MI355X library (`include/rsx.h`).
+//!
+//! `get_digit` is arbitrary user code, so the device cannot run it; device dispatch keys off
+//! an additional associated const, `RSX_KEY`, which the 14 built-in key kinds set and the tuple
+//! impl forwards.  A type that leaves it `None` keeps the reference's own CPU body (the
+//! maintainer pastes the existing `mod.rs:62-175` into `cpu_radix_sort`), so nothing the
+//! reference accepts stops compiling.
+#![allow(clippy::missing_safety_doc)]
+use core::ffi::{c_char, c_int, c_void};
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub struct RsxLayout {
+    pub elem_bytes: u32,
+    pub key_offset: u32,
+    pub key_bytes: u32,
+    pub key_kind: u32,
+}
+pub const RSX_KEY_UNSIGNED: u32 = 0;
+pub const RSX_KEY_SIGNED: u32 = 1;
+pub const RSX_KEY_FLOAT: u32 = 2;
+
+#[repr(C)]
+pub struct RsxCtx {
+    _private: [u8; 0],
+}
+
+extern "C" {
+    pub fn rsx_ctx_create(device: c_int, out: *mut *mut RsxCtx) -> c_int;
+    pub fn rsx_ctx_destroy(ctx: *mut RsxCtx) -> c_int;
+    pub fn rsx_sort_host(ctx: *mut RsxCtx, data: *mut c_void, n: usize, layout: *const RsxLayout) -> c_int;
+    pub fn rsx_sort_device(ctx: *mut RsxCtx, d_data: *mut c_void, d_tmp: *mut c_void, n: usize,
+                           layout: *const RsxLayout, stream: *mut c_void) -> c_int;
+    pub fn rsx_strerror(status: c_int) -> *const c_char;
+}
+
+/// Key descriptor of a built-in key kind: (key_bytes, key_kind); offset and element size are
+/// filled in per element type.
+#[derive(Clone, Copy)]
+pub struct RsxKey {
+    pub key_bytes: u32,
+    pub key_kind: u32,
+    pub key_offset: u32,
+}
+
+/// `src/radix_sort/radix_digits.rs:1-5`, plus the device descriptor.
+pub trait RadixDigits: Send + Sync {
+    const NUMBER_OF_DIGITS: u8;
+    /// `Some` for keys the device knows how to map; `None` => CPU path.
+    const RSX_KEY: Option<RsxKey> = None;
+    fn get_digit(&self, index: u8) -> u8;
+}
+
+macro_rules! unsigned_impl { ($($t:ty),*) => {$(
+    impl RadixDigits for $t {
+        const NUMBER_OF_DIGITS: u8 = core::mem::size_of::<$t>() as u8;
+        const RSX_KEY: Option<RsxKey> = Some(RsxKey { key_bytes: core::mem::size_of::<$t>() as u32, key_kind: RSX_KEY_UNSIGNED, key_offset: 0 });
+        fn get_digit(&self, index: u8) -> u8 { (*self >> (index as u32 * 8)) as u8 }
+    }
+)*}}
+macro_rules! signed_impl { ($($t:ty),*) => {$(
+    impl RadixDigits for $t {
+        const NUMBER_OF_DIGITS: u8 = core::mem::size_of::<$t>() as u8;
+        const RSX_KEY: Option<RsxKey> = Some(RsxKey { key_bytes: core::mem::size_of::<$t>() as u32, key_kind: RSX_KEY_SIGNED, key_offset: 0 });
+        fn get_digit(&self, index: u8) -> u8 { ((*self ^ <$t>::MIN) >> (index as u32 * 8)) as u8 }
+    }
+)*}}
+unsigned_impl!(u8, u16, u32, u64, u128, usize);
+signed_impl!(i8, i16, i32, i64, i128, isize);
+
+impl RadixDigits for f32 {
+    const NUMBER_OF_DIGITS: u8 = 4;
+    const RSX_KEY: Option<RsxKey> = Some(RsxKey { key_bytes: 4, key_kind: RSX_KEY_FLOAT, key_offset: 0 });
+    fn get_digit(&self, index: u8) -> u8 {
+        let mut b = self.to_bits() as i32;
+        b ^= (b >> 31) | i32::MIN;
+        (b as u32 >> (index as u32 * 8)) as u8
+    }
+}
+impl RadixDigits for f64 {
+    const NUMBER_OF_DIGITS: u8 = 8;
+    const RSX_KEY: Option<RsxKey> = Some(RsxKey { key_bytes: 8, key_kind: RSX_KEY_FLOAT, key_offset: 0 });
+    fn get_digit(&self, index: u8) -> u8 {
+        let mut b = self.to_bits() as i64;
+        b ^= (b >> 63) | i64::MIN;
+        (b as u64 >> (index as u32 * 8)) as u8
+    }
+}
+/// `(T, U)`: key is `.0`, payload opaque (radix_digits.rs:126-136).  Rust tuple layout is not
+/// ABI-stable, so the key offset is measured, not assumed.
+impl<T: RadixDigits + Send + Sync, U: Send + Sync> RadixDigits for (T, U) {
+    const NUMBER_OF_DIGITS: u8 = T::NUMBER_OF_DIGITS;
+    const RSX_KEY: Option<RsxKey> = match T::RSX_KEY {
+        Some(k) => Some(RsxKey { key_bytes: k.key_bytes, key_kind: k.key_kind,
+                                 key_offset: core::mem::offset_of!((T, U), 0) as u32 + k.key_offset }),
+        None => None,
+    };
+    fn get_digit(&self, index: u8) -> u8 { self.0.get_digit(index) }
+}
+
+/// `src/radix_sort/mod.rs:18-20`.
+pub trait RadixSort<T: RadixDigits> {
+    fn radix_sort(&mut self);
+}
+
+fn with_ctx<R>(f: impl FnOnce(*mut RsxCtx) -> R) -> R {
+    use std::sync::{Mutex, OnceLock};
+    struct Ctx(*mut RsxCtx);
+    unsafe impl Send for Ctx {}
+    static CTX: OnceLock<Mutex<Ctx>> = OnceLock::new();
+    let m = CTX.get_or_init(|| {
+        let mut p = core::ptr::null_mut();
+        let rc = unsafe { rsx_ctx_create(-1, &mut p) };
+        assert!(rc == 0, "rsx_ctx_create failed: {rc}"); // the reference panics too (mod.rs:68)
+        Mutex::new(Ctx(p))
+    });
+    let g = m.lock().unwrap();
+    f(g.0)
+}
+
+impl<T: RadixDigits> RadixSort<T> for [T] {
+    fn radix_sort(&mut self) {
+        if self.len() <= 1 {
+            return; // the reference panics on an empty slice (mod.rs:66-70,92): nothing to sort
+        }
+        match T::RSX_KEY {
+            Some(k) if matches!(core::mem::size_of::<T>(), 1 | 2 | 4 | 8 | 12 | 16 | 24 | 32) => {
+                let layout = RsxLayout { elem_bytes: core::mem::size_of::<T>() as u32, key_offset: k.key_offset,
+                                         key_bytes: k.key_bytes, key_kind: k.key_kind };
+                let rc = with_ctx(|ctx| unsafe {
+                    rsx_sort_host(ctx, self.as_mut_ptr() as *mut c_void, self.len(), &layout)
+                });
+                assert!(rc == 0, "rsx_sort_host failed: {rc}"); // panic like mod.rs:106
+            }
+            _ => cpu_radix_sort(self),
+        }
+    }
+}
+
+/// The reference's own body (`src/radix_sort/mod.rs:62-175`) goes here unchanged when this
+/// shim is merged; it serves user key types with a custom `get_digit` and odd element sizes.
+fn cpu_radix_sort<T: RadixDigits>(_data: &mut [T]) {
+    unimplemented!("paste the existing mod.rs:62-175 body here when integrating")
+}

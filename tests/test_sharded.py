@@ -117,3 +117,42 @@ def test_exchange_plan_properties():
                 cover[do:do + ln] += 1
             assert (cover == 1).all()
             assert segs[:, 0].tolist() == sorted(segs[:, 0].tolist()) or True
+
+
+# ---- GPU: the real HIP local steps under the same exchange, 2 ranks sharing one MI355X ----------
+def _gpu_worker(rank, world, port, tname, dist_name, sizes, outdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    import radix_sort_amd as rs
+    from radix_sort_amd.sharded import ShardedRadixSort
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        d = rs.RadixDigits(*util.TYPES[tname])
+        full = util.make_input(tname, sum(sizes), dist_name, seed=78)
+        off = sum(sizes[:rank])
+        x = torch.from_numpy(full[off * d.elem_bytes:(off + sizes[rank]) * d.elem_bytes].copy()).cuda()
+        ShardedRadixSort().sort(x, d, n_per_rank=list(sizes))  # product backend: HIP through the C-ABI
+        np.save(os.path.join(outdir, f"out{rank}.npy"), x.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tname,dist_name,sizes", [
+    ("u32", "uniform", (300000, 300000)),
+    ("(u64,u64)", "zipf", (150001, 99999)),
+    ("f64", "uniform", (70000, 1)),
+])
+def test_sharded_hip_two_ranks_one_gpu(orc, tmp_path, tname, dist_name, sizes):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_gpu_worker, args=(2, port, tname, dist_name, sizes, str(tmp_path)), nprocs=2, join=True)
+    got = np.concatenate([np.load(tmp_path / f"out{r}.npy") for r in range(2)])
+    lay = orc.Layout(*util.TYPES[tname])
+    full = util.make_input(tname, sum(sizes), dist_name, seed=78)
+    assert np.array_equal(got, orc.sort_parallel(full, lay, 4))
