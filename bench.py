@@ -153,6 +153,16 @@ def cpu_baseline(t_name, n_full, target_seconds=15.0):
                       f"timed like main.rs:32-34 (temp alloc + page touch inside)"}
 
 
+def pmc_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json; bench.py cannot run the profiler on itself)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get(workload, {}).get("traffic_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,7 +207,8 @@ def main():
                 "frac": (res.get("sweep_gbps") or 0.0) / HBM_PEAK_GBPS,
                 "algorithmic_bytes_per_launch": 2 * n * d.elem_bytes,
                 "avg_launch_ms": res.get("sweep_ms_per_launch"), "launches_timed": res.get("sweep_launches"),
-                "traffic": None,
+                "traffic": pmc_traffic(args.workload),
+                "traffic_note": "HBM bytes per launch, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, separate passes), profiles/pmc_traffic.json",
             },
         }
         extra = {}
