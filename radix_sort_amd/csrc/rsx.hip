@@ -26,9 +26,9 @@ constexpr size_t OFF_J0 = 0;
 constexpr size_t OFF_J1 = OFF_J0 + J_BYTES;
 constexpr size_t OFF_BASE = OFF_J1 + J_BYTES;       // [MAX_REGIONS][256] write cursors
 constexpr size_t OFF_TICKETS = OFF_BASE + J_BYTES;  // [MAX_REGIONS] u32
-constexpr size_t OFF_ERROR = OFF_TICKETS + 64;
+constexpr size_t OFF_ERROR = OFF_TICKETS + 128;  // tickets[16] + roll-call words
 constexpr size_t OFF_DBG = OFF_ERROR + 64;  // 8 diagnostic counters
-constexpr size_t AUX_BYTES = OFF_DBG + 64;
+constexpr size_t AUX_BYTES = OFF_DBG + 1024;  // 16 waves x 8 diagnostic counters
 }  // namespace
 
 struct rsx_ctx {
@@ -266,6 +266,7 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
     a.next = make_spec(L, NEXT ? digit + 1 : digit);
     a.dbg = ctx->dbg;
     a.stagger = ctx->stagger;
+    a.num_cu = (uint32_t)ctx->num_cu;
     a.dbg_cnt = reinterpret_cast<unsigned long long*>(ctx->aux + OFF_DBG);
     const size_t lds = (size_t)TILE * ES + (SWEEP_WG / WAVE) * RADIX * sizeof(uint16_t) +
                        (NEXT ? (size_t)MAX_REGIONS * RADIX * sizeof(uint32_t) : 0) + 64;
@@ -281,8 +282,28 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
     const uint64_t total_tiles = (g.n + TILE - 1) / TILE + g.num_regions;
     uint64_t grid = (uint64_t)ctx->num_cu * occ;
     if (grid > total_tiles) grid = total_tiles;
+    if (const char* o = std::getenv("RSX_OCC")) grid = (uint64_t)ctx->num_cu * std::atoi(o);  // tuning only
+    {   // static mode: workgroups per region, proportional to the region's tile count, >= 1 each
+        const uint32_t NR = g.num_regions;
+        const uint64_t tpr = 1ull << (g.region_shift - log2u(TILE));
+        const uint64_t real_tiles = (g.n + TILE - 1) / TILE;
+        uint64_t cum = 0;
+        for (uint32_t r = 0; r < NR; ++r) {
+            a.wg_first[r] = (uint16_t)(cum * grid / real_tiles);
+            const uint64_t left = real_tiles - cum;
+            cum += left < tpr ? left : tpr;
+        }
+        a.wg_first[NR] = (uint16_t)grid;
+        for (uint32_t r = 0; r < NR; ++r)  // at least one workgroup per region
+            if (a.wg_first[r + 1] <= a.wg_first[r]) a.wg_first[r + 1] = a.wg_first[r] + 1;
+        for (uint32_t r = NR; r-- > 0;) {
+            const uint32_t cap = (uint32_t)grid - (NR - r);
+            if (a.wg_first[r] > cap) a.wg_first[r] = (uint16_t)cap;
+        }
+        a.wg_first[NR] = (uint16_t)grid;
+        for (uint32_t r = NR + 1; r <= (uint32_t)MAX_REGIONS; ++r) a.wg_first[r] = (uint16_t)grid;
+    }
     if (ctx->dbg & 0x200u) std::fprintf(stderr, "[rsx] sweep ES=%d NEXT=%d occ=%d grid=%llu lds=%zu tiles=%llu regions=%u\n", ES, (int)NEXT, occ, (unsigned long long)grid, lds, (unsigned long long)total_tiles, g.num_regions);
-    if (const char* o = std::getenv("RSX_OCC")) grid = (uint64_t)ctx->num_cu * std::atoi(o);
     LaunchTimer lt(ctx, RSX_PROF_SWEEP, st);
     hipLaunchKernelGGL(kern, dim3((uint32_t)grid), dim3(SWEEP_WG), lds, st, a);
     RSX_HIP(hipGetLastError());
@@ -465,8 +486,8 @@ int rsx_debug_counters(rsx_ctx* ctx, unsigned long long* out8, int reset) try {
     std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard g(ctx->device);
     RSX_HIP(hipDeviceSynchronize());
-    RSX_HIP(hipMemcpy(out8, ctx->aux + OFF_DBG, 64, hipMemcpyDeviceToHost));
-    if (reset) RSX_HIP(hipMemset(ctx->aux + OFF_DBG, 0, 64));
+    RSX_HIP(hipMemcpy(out8, ctx->aux + OFF_DBG, 1024, hipMemcpyDeviceToHost));  // caller passes 128 u64
+    if (reset) RSX_HIP(hipMemset(ctx->aux + OFF_DBG, 0, 1024));
     return RSX_OK;
 } catch (...) {
     return RSX_ERR_HIP;

@@ -128,6 +128,54 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+// The same match as ONE hand-scheduled block of exactly 32 VALU: three rotating ballot
+// destinations (VCC and two SGPR pairs named in the clobber list) and three rotating bit
+// registers, ordered so that every v_cmp result is first read >= 3 instructions later -- the
+// wait states hipcc pads with s_nop (about 10 issue slots per key in its own schedule of
+// match_digit) are covered by useful work.  The sweep kernel is VALU-issue-bound in its
+// match phase (removing the match altogether shortens a u32 pass by a quarter), so issue
+// slots are what counts.
+__device__ __forceinline__ uint64_t match_digit_sched(uint32_t d) {
+    uint32_t lo, hi, t0, t1, t2;
+    asm volatile(
+        "v_bfe_i32 %2, %5, 0, 1\n\t"
+        "v_bfe_i32 %3, %5, 1, 1\n\t"
+        "v_cmp_ne_u32_e64 vcc, 0, %2\n\t"
+        "v_cmp_ne_u32_e64 s[96:97], 0, %3\n\t"
+        "v_bfe_i32 %4, %5, 2, 1\n\t"
+        "v_cmp_ne_u32_e64 s[98:99], 0, %4\n\t"
+        "v_bitop3_b32 %0, -1, vcc_lo, %2 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, -1, vcc_hi, %2 bitop3:0x90\n\t"
+        "v_bfe_i32 %2, %5, 3, 1\n\t"
+        "v_cmp_ne_u32_e64 vcc, 0, %2\n\t"
+        "v_bitop3_b32 %0, %0, s96, %3 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, s97, %3 bitop3:0x90\n\t"
+        "v_bfe_i32 %3, %5, 4, 1\n\t"
+        "v_cmp_ne_u32_e64 s[96:97], 0, %3\n\t"
+        "v_bitop3_b32 %0, %0, s98, %4 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, s99, %4 bitop3:0x90\n\t"
+        "v_bfe_i32 %4, %5, 5, 1\n\t"
+        "v_cmp_ne_u32_e64 s[98:99], 0, %4\n\t"
+        "v_bitop3_b32 %0, %0, vcc_lo, %2 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, vcc_hi, %2 bitop3:0x90\n\t"
+        "v_bfe_i32 %2, %5, 6, 1\n\t"
+        "v_cmp_ne_u32_e64 vcc, 0, %2\n\t"
+        "v_bitop3_b32 %0, %0, s96, %3 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, s97, %3 bitop3:0x90\n\t"
+        "v_bfe_i32 %3, %5, 7, 1\n\t"
+        "v_cmp_ne_u32_e64 s[96:97], 0, %3\n\t"
+        "v_bitop3_b32 %0, %0, s98, %4 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, s99, %4 bitop3:0x90\n\t"
+        "v_bitop3_b32 %0, %0, vcc_lo, %2 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, vcc_hi, %2 bitop3:0x90\n\t"
+        "v_bitop3_b32 %0, %0, s96, %3 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, s97, %3 bitop3:0x90"
+        : "=&v"(lo), "=&v"(hi), "=&v"(t0), "=&v"(t1), "=&v"(t2)
+        : "v"(d)
+        : "vcc", "s96", "s97", "s98", "s99");
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // ----------------------------------------------------------------- regions --
 // Every pass sees its INPUT as up to MAX_REGIONS equal position ranges ("regions"):
 //   region r = elements [r << region_shift, min((r + 1) << region_shift, n)).
@@ -232,7 +280,7 @@ __global__ __launch_bounds__(256) void rsx_prefix_kernel(const unsigned long lon
     }
     if (jnext)
         for (uint32_t r = 0; r < MAX_REGIONS; ++r) jnext[r * RADIX + tid] = 0;
-    if (tid < MAX_REGIONS) tickets[tid] = 0;
+    if (tid < MAX_REGIONS + 2) tickets[tid] = 0;  // + roll-call words of the sweep
 }
 
 // -------------------------------------------------------------------- sweep --
@@ -259,13 +307,16 @@ struct SweepArgs {
     RegionGeom g;
     const uint64_t* region_base;  // [num_regions][256] write cursor (elements) at region start
     void* status;                 // [num_regions << (region_shift - log2 TILE)][256], zeroed
-    uint32_t* tickets;            // [MAX_REGIONS] per-region tile counters, zeroed
+    uint32_t* tickets;            // [MAX_REGIONS] per-region tile counters, zeroed; [MAX_REGIONS], [MAX_REGIONS+1]:
+                                  // arrival count and mode word of the start-up roll call, zeroed
+    uint16_t wg_first[MAX_REGIONS + 1];  // static mode: region r is served by workgroups [wg_first[r], wg_first[r+1])
     unsigned long long* jnext;    // [MAX_REGIONS][256] next pass's count matrix (accumulated), or null
     uint32_t* error;              // set non-zero if a bounded spin gave up
     DigitSpec spec;               // this pass's digit
     DigitSpec next;               // next pass's digit (when jnext != null)
     uint32_t dbg;                 // timing-only ablation switches (0 in production)
-    uint32_t stagger;             // start delay step between the workgroups of one chain (x 512 cycles)
+    uint32_t stagger;             // start delay between the workgroups sharing a CU (x 512 cycles)
+    uint32_t num_cu;
     unsigned long long* dbg_cnt;  // [8] diagnostic counters (dbg & 0x100)
 };
 
@@ -358,8 +409,9 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : KPT * (ES < 4 ? 4 : ES) > 64 
     using E = Elem<ES>;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr size_t TILE_BYTES = (size_t)TILE * sizeof(E);
     E* s_elems = reinterpret_cast<E*>(smem);                                           // [TILE]
-    uint32_t* s_whist2 = reinterpret_cast<uint32_t*>(smem + (size_t)TILE * sizeof(E)); // [NWAVE][128]: 2 x 16-bit counters per word
+    uint32_t* s_whist2 = reinterpret_cast<uint32_t*>(smem + TILE_BYTES);               // [NWAVE][128]: 2 x 16-bit counters per word
     uint16_t* s_whist = reinterpret_cast<uint16_t*>(s_whist2);                         // [NWAVE][256] same memory
     uint64_t* s_base = reinterpret_cast<uint64_t*>(s_whist2);                          // [256], aliases s_whist (dead by then)
     uint32_t* s_jn = s_whist2 + NWAVE * (RADIX / 2);                                   // [MAX_REGIONS][256] (NEXT)
@@ -375,15 +427,55 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : KPT * (ES < 4 ? 4 : ES) > 64 
     if (NEXT)
         for (uint32_t i = threadIdx.x; i < MAX_REGIONS * RADIX; i += WG) s_jn[i] = 0;
 
-    // ---- tile tickets (thread 0) ----------------------------------------------------
-    // tiles of region r are handed out in order by tickets[r], so every lower tile of a
-    // chain is already running when a tile starts; a workgroup walks the regions round-robin.
-    uint32_t rr = (a.dbg & 0x800u) ? (blockIdx.x * NR / gridDim.x) % NR : blockIdx.x % NR;  // region the next ticket is drawn from
-    // Regions are a power of two apart, so chains that advance in lockstep hit the same HBM
-    // banks (different rows) at the same time; chain r therefore starts r * stagger * 512 cycles
-    // late and stays that many tiles behind its neighbours for the whole pass.
-    if (threadIdx.x == 0)
-        for (uint32_t i = 0, n = rr * a.stagger; i < n; ++i) __builtin_amdgcn_s_sleep(8);
+    // ---- who sorts which tile ----------------------------------------------------------
+    // Tiles of a region form a chain and must START in order (a tile only waits for lower tiles
+    // of its chain).  Two ways to guarantee that:
+    //  * dynamic: an agent-scope ticket counter per region (always safe; costs an atomic round
+    //    trip of 1.5-3.5 us at every tile start, ~19 % of a tile);
+    //  * static: workgroup j of the M serving a region takes tiles j, j+M, j+2M, ... -- no
+    //    atomics and the next tile is known early, but it needs every workgroup of the grid to
+    //    be resident at once.  That is established, not assumed: a roll call at kernel start.
+    //    Every workgroup adds itself to a counter and polls it for a bounded time; the first
+    //    to see the full count (or to time out) fixes the mode for everybody with one CAS.
+    //    A full count proves all workgroups are running, and a running workgroup stays
+    //    resident until it exits.
+    if (threadIdx.x == 0) {
+        uint32_t mode = 2;
+        if (!(a.dbg & 0x2000u)) {
+            uint32_t* arrive = a.tickets + MAX_REGIONS;
+            uint32_t* modew = a.tickets + MAX_REGIONS + 1;
+            __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            uint32_t seen = 0;
+            do {
+                seen = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (seen == gridDim.x) break;
+                __builtin_amdgcn_s_sleep(4);
+            } while (__builtin_amdgcn_s_memtime() - t0 < 200000ull);
+            uint32_t expected = 0;
+            __hip_atomic_compare_exchange_strong(modew, &expected, seen == gridDim.x ? 1u : 2u, __ATOMIC_RELAXED,
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mode = __hip_atomic_load(modew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_misc[3] = mode;
+    }
+    __syncthreads();
+    const bool static_mode = __builtin_amdgcn_readfirstlane(s_misc[3]) == 1u;
+    // workgroup index, XCD-major (blocks are dealt round-robin over the 8 XCDs): the workgroups of
+    // one chain then share an XCD, which makes their status hand-offs faster -- never a
+    // correctness matter
+    const uint32_t bx = (gridDim.x % 8u == 0u && !(a.dbg & 0x4000u)) ? (blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u : blockIdx.x;
+    uint32_t home = 0;
+    while (home + 1 < NR && bx >= a.wg_first[home + 1]) ++home;
+    const uint32_t st_step = a.wg_first[home + 1] - a.wg_first[home];  // M: workgroups serving my region
+    uint32_t st_k = bx - a.wg_first[home];                             // my next tile in static mode
+    uint32_t st_nt;
+    {
+        const uint64_t rbeg = (uint64_t)home << a.g.region_shift;
+        const uint64_t rlen = (a.g.n - rbeg) < region_len ? (a.g.n - rbeg) : region_len;
+        st_nt = (uint32_t)((rlen + TILE - 1) >> TILE_LOG);
+    }
+    uint32_t rr = home;  // dynamic mode: region the next ticket is drawn from
     uint32_t alive = NR;            // regions not yet seen exhausted
     uint32_t exhausted = 0;         // bitmask of exhausted regions
     // resolve ticket `k` of region `r` into a tile, drawing further tickets while regions run dry
@@ -425,16 +517,26 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : KPT * (ES < 4 ? 4 : ES) > 64 
         uint32_t* my_hist2 = s_whist2 + wave * (RADIX / 2);
         uint16_t* my_hist = s_whist + wave * RADIX;
         reinterpret_cast<uint64_t*>(my_hist2)[lane] = 0;  // each wave clears its 256 16-bit counters
-        // The ticket is drawn when the tile starts, so ticket order == start order inside a chain.
-        // (Drawing it earlier hides the atomic's round trip but makes a workgroup sit on a ticket
-        // while the tiles behind it in the chain already wait for its aggregate: measured slower.)
-        if (tid == 0)
-            resolve(rr, __hip_atomic_fetch_add(&a.tickets[rr], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0);
-        __syncthreads();
-        RSX_STAMP(0);
-        if (s_misc[0] == 0) break;
-        const uint32_t reg = s_misc[1];
-        const uint32_t kt = s_misc[2];
+        // dynamic mode: the ticket is drawn when the tile starts, so ticket order == start order inside
+        // a chain.  (Drawing it earlier hides the atomic's round trip but makes a workgroup sit on a
+        // ticket while the tiles behind it in the chain already wait for its aggregate: measured slower.)
+        uint32_t reg, kt;
+        if (static_mode) {  // wave-uniform
+            __syncthreads();
+            RSX_STAMP(0);
+            if (st_k >= st_nt) break;
+            reg = home;
+            kt = st_k;
+            st_k += st_step;
+        } else {
+            if (tid == 0)
+                resolve(rr, __hip_atomic_fetch_add(&a.tickets[rr], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0);
+            __syncthreads();
+            RSX_STAMP(0);
+            if (__builtin_amdgcn_readfirstlane(s_misc[0]) == 0) break;
+            reg = __builtin_amdgcn_readfirstlane(s_misc[1]);
+            kt = __builtin_amdgcn_readfirstlane(s_misc[2]);
+        }
 
         const uint64_t tile_base = ((uint64_t)reg << a.g.region_shift) + ((uint64_t)kt << TILE_LOG);
         const uint64_t rend = ((uint64_t)(reg + 1) << a.g.region_shift) < a.g.n ? ((uint64_t)(reg + 1) << a.g.region_shift) : a.g.n;
@@ -458,7 +560,7 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : KPT * (ES < 4 ? 4 : ES) > 64 
         if (full) {  // branch-free body (the common case)
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
-                const uint64_t m = match_digit(elem_digit<ES, FLT>(e[j], a.spec));
+                const uint64_t m = match_digit_sched(elem_digit<ES, FLT>(e[j], a.spec));
                 pk[j / 2] |= (mbcnt64(m) | (((uint32_t)__popcll(m) - 1u) << 6)) << (16 * (j & 1));
                 // two matches in flight hide the SGPR-write -> VALU-read wait states; more only costs VGPRs
                 if (j % RSX_MATCH_ILP == RSX_MATCH_ILP - 1) __builtin_amdgcn_sched_barrier(0);
@@ -618,8 +720,8 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : KPT * (ES < 4 ? 4 : ES) > 64 
         RSX_STAMP(6);
     }
 #ifdef RSX_STAMPS
-    if (threadIdx.x == 0)
-        for (int k = 0; k < 7; ++k) atomicAdd(&a.dbg_cnt[k], stamp_acc[k]);
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 7; ++k) atomicAdd(&a.dbg_cnt[(threadIdx.x >> 6) * 8 + k], stamp_acc[k]);
 #endif
 
     if (NEXT) {  // hand this workgroup's share of the next count matrix over

@@ -8,7 +8,7 @@ L = _lib.load()
 L.rsx_debug_counters.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
 d = rs.PRIMITIVES["u32"]; n = 1 << 28
 x = torch.empty(n * 4, dtype=torch.uint8, device="cuda"); tmp = torch.empty_like(x)
-out = (ctypes.c_ulonglong * 8)()
+out = (ctypes.c_ulonglong * 128)()
 for it in range(3):
     ctx.generate_device(x.data_ptr(), n, d, rs.GEN_UNIFORM, it)
     torch.cuda.synchronize()

@@ -8,7 +8,7 @@ L.rsx_debug_counters.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulongl
 key = sys.argv[1] if len(sys.argv) > 1 else "u32"
 d = rs.PRIMITIVES[key]; n = 1 << 28
 x = torch.empty(n * d.elem_bytes, dtype=torch.uint8, device="cuda"); tmp = torch.empty_like(x)
-out = (ctypes.c_ulonglong * 8)()
+out = (ctypes.c_ulonglong * 128)()
 names = ["ticket+barrier", "load+match", "rank+barrier", "count/scan/offsets", "lds-scatter+barrier", "lookback+barrier", "writeout+barrier"]
 for it in range(2):
     ctx.generate_device(x.data_ptr(), n, d, rs.GEN_UNIFORM, it)
@@ -16,5 +16,8 @@ for it in range(2):
     L.rsx_debug_counters(ctx._h, out, 1)
     rs.radix_sort(x, digits=d, tmp=tmp)
     L.rsx_debug_counters(ctx._h, out, 1)
-    tot = sum(out[k] for k in range(7))
-    print(" | ".join(f"{names[k]} {100*out[k]/tot:.1f}%" for k in range(7)), f"| total cycles/WG-tile {tot/ (d.key_bytes * n / (512*(16 if d.elem_bytes<=4 else 64//d.elem_bytes))):.0f}")
+    ntile = d.key_bytes * n / (512*(16 if d.elem_bytes<=4 else 64//d.elem_bytes))
+    for w in range(8):
+        o = out[w*8:(w+1)*8]
+        tot = sum(o[k] for k in range(7))
+        print(f"wave {w}: " + " | ".join(f"{names[k][:14]} {o[k]/ntile:6.0f}" for k in range(7)), f"| total {tot/ntile:.0f}")
