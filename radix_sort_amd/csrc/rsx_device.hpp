@@ -70,11 +70,22 @@ template <int ES>
 __device__ __forceinline__ uint32_t elem_word(const Elem<ES>& e, uint32_t wi) {  // wi is wave-uniform
     if constexpr (ES < 4) {
         return e.w[0];
+    } else if constexpr (ES == 4) {
+        return e.w[0];
+    } else if constexpr (ES == 8) {
+        return wi ? e.w[1] : e.w[0];
     } else {
+        // A select chain over >2 words is turned by hipcc into a dynamically indexed read of the
+        // element, which puts every element into scratch memory (runtime-indexed register arrays
+        // are not a thing).  A bit-select (v_bfi) on an opaque wave-uniform mask keeps them in VGPRs.
         constexpr int NW = ES / 4;
         uint32_t word = e.w[0];
 #pragma unroll
-        for (int i = 1; i < NW; ++i) word = (wi == (uint32_t)i) ? e.w[i] : word;
+        for (int i = 1; i < NW; ++i) {
+            uint32_t pick = (wi == (uint32_t)i) ? ~0u : 0u;
+            asm("" : "+v"(pick));  // opaque: otherwise recognised as a select again
+            word = (word & ~pick) | (e.w[i] & pick);
+        }
         return word;
     }
 }
@@ -346,6 +357,9 @@ struct SweepArgs {
 #ifndef RSX_MATCH_ILP
 #define RSX_MATCH_ILP 2
 #endif
+#ifndef RSX_PREFETCH_ALL
+#define RSX_PREFETCH_ALL 0
+#endif
 
 // Makes the compiler forget what it knows about the element registers: digits derived from them
 // are then re-derived where needed (2 VALU) instead of being kept live across phases (1 VGPR each).
@@ -403,6 +417,9 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : KPT * (ES < 4 ? 4 : ES) > 64 
     constexpr int NWAVE = WG / WAVE;
     constexpr int TILE = WG * KPT;
     constexpr int TILE_LOG = __builtin_ctz(TILE);
+    // next-tile prefetch keeps the element registers live through the write-out: only where that fits
+    // the VGPR budget without spilling (u32 x 16 keys does not at 80 VGPRs, and is VALU-bound anyway)
+    constexpr bool PREFETCH = RSX_PREFETCH_ALL != 0;  // measured slower on u32 and u64: off
     static_assert((TILE & (TILE - 1)) == 0, "tile size must be a power of two (regions are whole tiles)");
     static_assert(WG >= RADIX, "need one thread per digit");
     static_assert(TILE <= 65536 / 2, "wave counters are 16 bit");
@@ -507,6 +524,8 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : KPT * (ES < 4 ? 4 : ES) > 64 
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
 #endif
+    E e[KPT];
+    bool preloaded = false;  // static mode: this tile's loads were issued during the previous tile
     while (true) {
         // thread coordinates are re-derived per tile from an opaque copy of threadIdx: otherwise
         // every tid-derived address (dozens of VGPRs) is hoisted out of this loop and spilled
@@ -549,8 +568,7 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : KPT * (ES < 4 ? 4 : ES) > 64 
 
         // ---- load + digit + match: independent -> ILP ------------
         __builtin_amdgcn_s_setprio(0);
-        E e[KPT];
-        load_tile<ES, KPT>(e, src + tile_base, seg, valid, full);
+        if (!preloaded) load_tile<ES, KPT>(e, src + tile_base, seg, valid, full);
         // per element 16 bits of bookkeeping, two elements per VGPR: first
         // (lanes below me with my digit) | (size of my digit group - 1) << 6, later the tile rank.
         // The digit itself is re-derived from the element when needed (2 VALU) instead of kept.
@@ -644,6 +662,16 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : KPT * (ES < 4 ? 4 : ES) > 64 
         }
         __syncthreads();  // s_whist is dead from here: s_base takes its place
         RSX_STAMP(4);
+        // static mode knows its next tile: its loads are issued now (the element registers are
+        // free) and fly during the look-back and the write-out, so reads overlap writes
+        preloaded = false;
+        if (static_mode && PREFETCH && st_k < st_nt) {
+            const uint64_t tb = ((uint64_t)home << a.g.region_shift) + ((uint64_t)st_k << TILE_LOG);
+            const uint64_t re = ((uint64_t)(home + 1) << a.g.region_shift) < a.g.n ? ((uint64_t)(home + 1) << a.g.region_shift) : a.g.n;
+            const bool fl = re - tb >= (uint64_t)TILE;
+            load_tile<ES, KPT>(e, src + tb, seg, fl ? (uint32_t)TILE : (uint32_t)(re - tb), fl);
+            preloaded = true;
+        }
 
         // ---- decoupled look-back inside the region's chain -----------------------
         if (tid < RADIX) {
