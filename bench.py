@@ -39,6 +39,9 @@ WORKLOADS = {
     "step16-256m-u32": ("u32", 28, "step", 16.0, "256M u32 step-uniform(16) keys"),
     "zipf-256m-u64": ("u64", 28, "zipf", 1.0, "256M u64 Zipf(s=1) keys"),
     "pairs-256m-u32u32": ("(u32,u32)", 28, "uniform", 0.0, "256M (u32,u32) pairs (reference bench type, main.rs:112)"),
+    "f32-256m": ("f32", 28, "uniform", 0.0, "256M f32 keys (uniform bit patterns: NaNs, infinities, both signs)"),
+    "i32-256m": ("i32", 28, "uniform", 0.0, "256M i32 uniform keys"),
+    "f64-128m": ("f64", 27, "uniform", 0.0, "128M f64 keys (uniform bit patterns)"),
     "pairs-128m-u64u64": ("(u64,u64)", 27, "uniform", 0.0, "128M (u64,u64) pairs (reference bench type, main.rs:123)"),
 }
 EXTRA_DEFAULT = ["target-1b-u32", "c3-1b-u64", "zipf-256m-u32", "step16-256m-u32"]

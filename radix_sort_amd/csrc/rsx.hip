@@ -175,6 +175,7 @@ DigitSpec make_spec(const rsx_layout* L, uint32_t digit) {
         s.top_shift = 8 * top + 7;
     }
     s.flip = (L->key_kind != RSX_KEY_UNSIGNED && digit == L->key_bytes - 1) ? 0x80u : 0u;
+    s.fsign = L->key_kind == RSX_KEY_FLOAT ? ~0u : 0u;
     return s;
 }
 
@@ -228,9 +229,8 @@ int launch_hist_t(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_
 template <int ES>
 int launch_hist(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_layout* L, uint32_t digit,
                 unsigned long long* J, hipStream_t st) {
-    if constexpr (ES >= 4) {
-        if (L->key_kind == RSX_KEY_FLOAT) return launch_hist_t<ES, true>(ctx, src, g, L, digit, J, st);
-    }
+    if (L->key_kind == RSX_KEY_FLOAT || (L->key_kind == RSX_KEY_SIGNED && digit + 1 == L->key_bytes))
+        return launch_hist_t<ES, true>(ctx, src, g, L, digit, J, st);
     return launch_hist_t<ES, false>(ctx, src, g, L, digit, J, st);
 }
 
@@ -245,7 +245,27 @@ int launch_prefix(rsx_ctx* ctx, const RegionGeom& g, const unsigned long long* J
 }
 
 // ---- scatter phase: one sweep pass -------------------------------------------------------------
-template <int ES, typename S, bool FLT, bool NEXT>
+// the per-dword masks of the signed/float key map (KeyXform in rsx_device.hpp)
+KeyXform make_xform(const rsx_layout* L) {
+    KeyXform x;
+    std::memset(&x, 0, sizeof x);
+    if (L->key_kind == RSX_KEY_UNSIGNED) return x;
+    const uint32_t top = L->key_offset + L->key_bytes - 1;
+    auto word_of = [&](uint32_t byte) { return L->elem_bytes >= 4 ? byte >> 2 : 0u; };
+    auto bit_of = [&](uint32_t byte) { return L->elem_bytes >= 4 ? 8 * (byte & 3) : 8 * byte; };
+    const uint32_t sw = word_of(top);
+    const uint32_t sbit = 1u << (bit_of(top) + 7);
+    x.sign[sw] = sbit;
+    x.xpos[sw] = sbit;
+    if (L->key_kind == RSX_KEY_SIGNED) {
+        x.xneg[sw] = sbit;
+    } else {
+        for (uint32_t b = L->key_offset; b <= top; ++b) x.xneg[word_of(b)] |= 0xFFu << bit_of(b);
+    }
+    return x;
+}
+
+template <int ES, typename S, int XF, bool NEXT>
 int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L,
                    uint32_t digit, unsigned long long* jnext, hipStream_t st) {
     constexpr int KPT = kpt_for(ES);
@@ -264,13 +284,15 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
     a.error = error_of(ctx);
     a.spec = make_spec(L, digit);
     a.next = make_spec(L, NEXT ? digit + 1 : digit);
+    a.spec.flip = a.next.flip = 0;  // the sweep sees mapped keys: plain digits
+    a.xf = make_xform(L);
     a.dbg = ctx->dbg;
     a.stagger = ctx->stagger;
     a.num_cu = (uint32_t)ctx->num_cu;
     a.dbg_cnt = reinterpret_cast<unsigned long long*>(ctx->aux + OFF_DBG);
     const size_t lds = (size_t)TILE * ES + (SWEEP_WG / WAVE) * RADIX * sizeof(uint16_t) +
                        (NEXT ? (size_t)MAX_REGIONS * RADIX * sizeof(uint32_t) : 0) + 64;
-    auto kern = rsx_sweep_kernel<ES, KPT, SWEEP_WG, S, FLT, NEXT>;
+    auto kern = rsx_sweep_kernel<ES, KPT, SWEEP_WG, S, XF, NEXT>;
     static int occ = 0;  // per instantiation: resident workgroups per CU for this kernel
     if (occ == 0) {
         int o = 0;
@@ -310,25 +332,30 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
     return RSX_OK;
 }
 
-template <int ES, typename S, bool FLT>
+template <int ES, typename S, int XF>
 int launch_sweep_n(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L,
                    uint32_t digit, unsigned long long* jnext, hipStream_t st) {
-    if (jnext) return launch_sweep_t<ES, S, FLT, true>(ctx, src, dst, g, L, digit, jnext, st);
-    return launch_sweep_t<ES, S, FLT, false>(ctx, src, dst, g, L, digit, jnext, st);
+    if (jnext) return launch_sweep_t<ES, S, XF, true>(ctx, src, dst, g, L, digit, jnext, st);
+    return launch_sweep_t<ES, S, XF, false>(ctx, src, dst, g, L, digit, jnext, st);
+}
+
+// xf: bit 0 = map signed/float keys on load (first pass), bit 1 = map back on store (last pass)
+template <int ES, typename S>
+int launch_sweep_x(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L,
+                   uint32_t digit, unsigned long long* jnext, int xf, hipStream_t st) {
+    switch (L->key_kind == RSX_KEY_UNSIGNED ? 0 : xf) {
+        case 1: return launch_sweep_n<ES, S, 1>(ctx, src, dst, g, L, digit, jnext, st);
+        case 2: return launch_sweep_n<ES, S, 2>(ctx, src, dst, g, L, digit, jnext, st);
+        case 3: return launch_sweep_n<ES, S, 3>(ctx, src, dst, g, L, digit, jnext, st);
+        default: return launch_sweep_n<ES, S, 0>(ctx, src, dst, g, L, digit, jnext, st);
+    }
 }
 
 template <int ES>
 int launch_sweep(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L, uint32_t digit,
-                 unsigned long long* jnext, hipStream_t st) {
-    const bool small = status32(g);
-    if constexpr (ES >= 4) {  // float keys are 4 or 8 bytes wide
-        if (L->key_kind == RSX_KEY_FLOAT) {
-            if (small) return launch_sweep_n<ES, uint32_t, true>(ctx, src, dst, g, L, digit, jnext, st);
-            return launch_sweep_n<ES, uint64_t, true>(ctx, src, dst, g, L, digit, jnext, st);
-        }
-    }
-    if (small) return launch_sweep_n<ES, uint32_t, false>(ctx, src, dst, g, L, digit, jnext, st);
-    return launch_sweep_n<ES, uint64_t, false>(ctx, src, dst, g, L, digit, jnext, st);
+                 unsigned long long* jnext, int xf, hipStream_t st) {
+    if (status32(g)) return launch_sweep_x<ES, uint32_t>(ctx, src, dst, g, L, digit, jnext, xf, st);
+    return launch_sweep_x<ES, uint64_t>(ctx, src, dst, g, L, digit, jnext, xf, st);
 }
 
 #define RSX_DISPATCH_ES(es, FN, ...)                           \
@@ -349,8 +376,8 @@ int hist_dispatch(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_
     RSX_DISPATCH_ES(L->elem_bytes, launch_hist, ctx, src, g, L, digit, J, st)
 }
 int sweep_dispatch(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L,
-                   uint32_t digit, unsigned long long* jnext, hipStream_t st) {
-    RSX_DISPATCH_ES(L->elem_bytes, launch_sweep, ctx, src, dst, g, L, digit, jnext, st)
+                   uint32_t digit, unsigned long long* jnext, int xf, hipStream_t st) {
+    RSX_DISPATCH_ES(L->elem_bytes, launch_sweep, ctx, src, dst, g, L, digit, jnext, xf, st)
 }
 
 template <int ES>
@@ -557,7 +584,8 @@ int rsx_sort_device(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const rsx
         unsigned long long* jnext = (d + 1 < D) ? J_of(ctx, (d + 1) & 1) : nullptr;
         rc = launch_prefix(ctx, geom, J_of(ctx, d & 1), jnext, nullptr, st);  // mod.rs:110-120
         if (rc) return rc;
-        rc = sweep_dispatch(ctx, src, dst, geom, L, d, jnext, st);  // mod.rs:121-168
+        const int xf = (d == 0 ? 1 : 0) | (d + 1 == D ? 2 : 0);  // key map on at the first, off at the last pass
+        rc = sweep_dispatch(ctx, src, dst, geom, L, d, jnext, xf, st);  // mod.rs:121-168
         if (rc) return rc;
     }
     if (D % 2 == 1)  // odd-D copy-back (mod.rs:170-174)
@@ -649,7 +677,7 @@ int rsx_partition_device(rsx_ctx* ctx, const void* d_src, void* d_dst, size_t n,
     if (rc) return rc;
     rc = launch_prefix(ctx, geom, J_of(ctx, 0), nullptr, d_hist, st);
     if (rc) return rc;
-    return sweep_dispatch(ctx, d_src, d_dst, geom, L, digit, nullptr, st);
+    return sweep_dispatch(ctx, d_src, d_dst, geom, L, digit, nullptr, 3, st);  // a lone pass maps and unmaps
 } catch (...) {
     return RSX_ERR_HIP;
 }

@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace rsx {
 
 constexpr int WAVE = 64;
@@ -64,6 +66,7 @@ struct DigitSpec {
     uint32_t top_word;   // dword holding the key's top byte (sign bit)
     uint32_t top_shift;  // bit offset of the SIGN BIT inside that dword
     uint32_t flip;       // signed/float keys: 0x80 when the digit is the top byte, else 0
+    uint32_t fsign;      // float keys: all ones (a set sign bit flips every digit), else 0
 };
 
 template <int ES>
@@ -90,18 +93,47 @@ __device__ __forceinline__ uint32_t elem_word(const Elem<ES>& e, uint32_t wi) { 
     }
 }
 
-// get_digit of radix_digits.rs on one element.  FLT: f32/f64 keys (:103-124);
-// otherwise unsigned (:7-53, flip == 0) or signed (:55-101, flip == 0x80 on the top byte).
+// get_digit of radix_digits.rs on one element.  FLT == false: the digit byte as it is --
+// unsigned keys (:7-53) and every digit of a signed key except its top one.  FLT == true: the
+// general map -- f32/f64 keys (:103-124: negative -> all bits flipped, else the sign bit) and the
+// top digit of signed keys (:55-101: sign bit flipped); spec.fsign says which.
 template <int ES, bool FLT>
 __device__ __forceinline__ uint32_t elem_digit(const Elem<ES>& e, const DigitSpec& s) {
     uint32_t d = (elem_word<ES>(e, s.word) >> s.shift) & 0xFFu;
     if constexpr (FLT) {
-        const uint32_t neg = (uint32_t)((int32_t)(elem_word<ES>(e, s.top_word) << (31u - s.top_shift)) >> 31);
-        d ^= (neg & 0xFFu) | (~neg & s.flip);  // negative: flip every bit; else only the sign bit
-    } else {
-        d ^= s.flip;
+        const uint32_t neg = (uint32_t)((int32_t)(elem_word<ES>(e, s.top_word) << (31u - s.top_shift)) >> 31) & s.fsign;
+        d ^= (neg & 0xFFu) | (~neg & s.flip);
     }
     return d;
+}
+
+// Signed and float keys are sorted in their order-preserving unsigned form (radix_digits.rs:
+// x ^ MIN, :55-101; b ^ ((b >> 31) | MIN), :103-124).  Instead of mapping every digit of every
+// pass, the FIRST pass of a sort maps the key once while the elements sit in registers and
+// the LAST pass maps it back on the way out; the passes in between see plain unsigned digits.
+// Per element dword i (all wave-uniform, built on the host from rsx_layout):
+//   sign[i]  the key's sign bit if it lives in dword i, else 0
+//   xneg[i]  bits to flip when the key counts as negative: every key bit of dword i for floats,
+//            the sign bit for signed integers
+//   xpos[i]  bits to flip otherwise: the sign bit
+// Forward: "negative" = sign bit set.  Inverse: the mapped sign bit is the complement.
+struct KeyXform {
+    uint32_t sign[8];
+    uint32_t xneg[8];
+    uint32_t xpos[8];
+};
+
+template <int ES, bool INVERSE>
+__device__ __forceinline__ void key_map(Elem<ES>& e, const KeyXform& x) {
+    constexpr int NW = ES < 4 ? 1 : ES / 4;
+    uint32_t sbits = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) sbits |= (uint32_t)e.w[i] & x.sign[i];
+    const uint32_t neg = ((sbits != 0) != INVERSE) ? ~0u : 0u;
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+        e.w[i] = static_cast<typename std::remove_reference<decltype(e.w[0])>::type>(
+            (uint32_t)e.w[i] ^ ((neg & x.xneg[i]) | (~neg & x.xpos[i])));
 }
 
 // generic (slow-path) byte fetch used by the histogram kernel
@@ -325,6 +357,7 @@ struct SweepArgs {
     uint32_t* error;              // set non-zero if a bounded spin gave up
     DigitSpec spec;               // this pass's digit
     DigitSpec next;               // next pass's digit (when jnext != null)
+    KeyXform xf;                  // signed/float key map applied on load (XF & 1) / undone on store (XF & 2)
     uint32_t dbg;                 // timing-only ablation switches (0 in production)
     uint32_t stagger;             // start delay between the workgroups sharing a CU (x 512 cycles)
     uint32_t num_cu;
@@ -412,7 +445,7 @@ __device__ __forceinline__ void load_tile(Elem<ES> (&e)[KPT], const Elem<ES>* __
     }
 }
 
-template <int ES, int KPT, int WG, typename S, bool FLT, bool NEXT>
+template <int ES, int KPT, int WG, typename S, int XF, bool NEXT>
 __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : KPT * (ES < 4 ? 4 : ES) > 64 ? 4 : RSX_MINW)) void rsx_sweep_kernel(const SweepArgs a) {
     constexpr int NWAVE = WG / WAVE;
     constexpr int TILE = WG * KPT;
@@ -569,6 +602,10 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : KPT * (ES < 4 ? 4 : ES) > 64 
         // ---- load + digit + match: independent -> ILP ------------
         __builtin_amdgcn_s_setprio(0);
         if (!preloaded) load_tile<ES, KPT>(e, src + tile_base, seg, valid, full);
+        if constexpr ((XF & 1) != 0) {  // first pass of a sort: keys become order-preserving unsigned
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) key_map<ES, false>(e[j], a.xf);
+        }
         // per element 16 bits of bookkeeping, two elements per VGPR: first
         // (lanes below me with my digit) | (size of my digit group - 1) << 6, later the tile rank.
         // The digit itself is re-derived from the element when needed (2 VALU) instead of kept.
@@ -578,7 +615,7 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : KPT * (ES < 4 ? 4 : ES) > 64 
         if (full) {  // branch-free body (the common case)
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
-                const uint64_t m = match_digit_sched(elem_digit<ES, FLT>(e[j], a.spec));
+                const uint64_t m = match_digit_sched(elem_digit<ES, false>(e[j], a.spec));
                 pk[j / 2] |= (mbcnt64(m) | (((uint32_t)__popcll(m) - 1u) << 6)) << (16 * (j & 1));
                 // two matches in flight hide the SGPR-write -> VALU-read wait states; more only costs VGPRs
                 if (j % RSX_MATCH_ILP == RSX_MATCH_ILP - 1) __builtin_amdgcn_sched_barrier(0);
@@ -586,7 +623,7 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : KPT * (ES < 4 ? 4 : ES) > 64 
         } else {
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
-                const uint32_t d = (seg + j * WAVE >= valid) ? 255u : elem_digit<ES, FLT>(e[j], a.spec);
+                const uint32_t d = (seg + j * WAVE >= valid) ? 255u : elem_digit<ES, false>(e[j], a.spec);
                 const uint64_t m = match_digit(d);
                 pk[j / 2] |= (mbcnt64(m) | (((uint32_t)__popcll(m) - 1u) << 6)) << (16 * (j & 1));
                 if (j % RSX_MATCH_ILP == RSX_MATCH_ILP - 1) __builtin_amdgcn_sched_barrier(0);
@@ -600,7 +637,7 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : KPT * (ES < 4 ? 4 : ES) > 64 
         // nothing waits on the read: all 2*KPT LDS ops pipeline (LDS serves a wave in order).
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
-            const uint32_t d = (!full && seg + j * WAVE >= valid) ? 255u : elem_digit<ES, FLT>(e[j], a.spec);
+            const uint32_t d = (!full && seg + j * WAVE >= valid) ? 255u : elem_digit<ES, false>(e[j], a.spec);
             const uint32_t v = (pk[j / 2] >> (16 * (j & 1))) & 0xFFFFu;
             const uint32_t below = v & 63u;
             const uint32_t sh = (d & 1u) * 16u;  // two 16-bit counters per LDS word
@@ -657,7 +694,7 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : KPT * (ES < 4 ? 4 : ES) > 64 
         forget<ES, KPT>(e);
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
-            const uint32_t d = (!full && seg + j * WAVE >= valid) ? 255u : elem_digit<ES, FLT>(e[j], a.spec);
+            const uint32_t d = (!full && seg + j * WAVE >= valid) ? 255u : elem_digit<ES, false>(e[j], a.spec);
             s_elems[my_hist[d] + ((pk[j / 2] >> (16 * (j & 1))) & 0xFFFFu)] = e[j];
         }
         __syncthreads();  // s_whist is dead from here: s_base takes its place
@@ -723,10 +760,16 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : KPT * (ES < 4 ? 4 : ES) > 64 
                 for (int i = 0; i < KPT; ++i) {
                     const uint32_t p = i * WG + tid;
                     const E x = s_elems[p];
-                    const uint64_t idx = s_base[elem_digit<ES, FLT>(x, a.spec)] + p;
-                    dst[idx] = x;
+                    const uint64_t idx = s_base[elem_digit<ES, false>(x, a.spec)] + p;
+                    if constexpr ((XF & 2) != 0) {  // last pass: back to the caller's representation
+                        E y = x;
+                        key_map<ES, true>(y, a.xf);
+                        dst[idx] = y;
+                    } else {
+                        dst[idx] = x;
+                    }
                     if (NEXT && !(a.dbg & 16u))
-                        count_next(s_jn, ((uint32_t)(idx >> a.g.region_shift) << 8) | elem_digit<ES, FLT>(x, a.next));
+                        count_next(s_jn, ((uint32_t)(idx >> a.g.region_shift) << 8) | elem_digit<ES, false>(x, a.next));
                     // bound the look-ahead: x + 64-bit base per element in flight is 3 VGPRs each
                     if (i % 4 == 3) __builtin_amdgcn_sched_barrier(0);
                 }
@@ -736,10 +779,16 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : KPT * (ES < 4 ? 4 : ES) > 64 
                     const uint32_t p = i * WG + tid;
                     if (p < valid) {
                         const E x = s_elems[p];
-                        const uint64_t idx = s_base[elem_digit<ES, FLT>(x, a.spec)] + p;
-                        dst[idx] = x;
+                        const uint64_t idx = s_base[elem_digit<ES, false>(x, a.spec)] + p;
+                        if constexpr ((XF & 2) != 0) {
+                            E y = x;
+                            key_map<ES, true>(y, a.xf);
+                            dst[idx] = y;
+                        } else {
+                            dst[idx] = x;
+                        }
                         if (NEXT)
-                            count_next(s_jn, ((uint32_t)(idx >> a.g.region_shift) << 8) | elem_digit<ES, FLT>(x, a.next));
+                            count_next(s_jn, ((uint32_t)(idx >> a.g.region_shift) << 8) | elem_digit<ES, false>(x, a.next));
                     }
                 }
             }
