@@ -390,6 +390,9 @@ struct SweepArgs {
 #ifndef RSX_MATCH_ILP
 #define RSX_MATCH_ILP 2
 #endif
+#ifndef RSX_RANK_GROUP
+#define RSX_RANK_GROUP 4
+#endif
 #ifndef RSX_PREFETCH_ALL
 #define RSX_PREFETCH_ALL 0
 #endif
@@ -446,7 +449,10 @@ __device__ __forceinline__ void load_tile(Elem<ES> (&e)[KPT], const Elem<ES>* __
 }
 
 template <int ES, int KPT, int WG, typename S, int XF, bool NEXT>
-__global__ __launch_bounds__(WG, (WG == 1024 ? 8 : KPT * (ES < 4 ? 4 : ES) > 64 ? 4 : RSX_MINW)) void rsx_sweep_kernel(const SweepArgs a) {
+// VGPR budget: 4-byte (and narrower) keys carry 16 elements per thread and need ~104 VGPRs; capping
+// them at 80 (3 workgroups/CU) spills, and the spills cost more than the third workgroup buys
+// (measured: 0.82 -> 0.68 ms per 256M-key pass at 2 workgroups/CU without spills).
+__global__ __launch_bounds__(WG, (WG == 1024 ? 8 : (ES <= 4 || KPT * ES > 64) ? 4 : RSX_MINW)) void rsx_sweep_kernel(const SweepArgs a) {
     constexpr int NWAVE = WG / WAVE;
     constexpr int TILE = WG * KPT;
     constexpr int TILE_LOG = __builtin_ctz(TILE);
@@ -606,47 +612,46 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : KPT * (ES < 4 ? 4 : ES) > 64 
 #pragma unroll
             for (int j = 0; j < KPT; ++j) key_map<ES, false>(e[j], a.xf);
         }
-        // per element 16 bits of bookkeeping, two elements per VGPR: first
-        // (lanes below me with my digit) | (size of my digit group - 1) << 6, later the tile rank.
-        // The digit itself is re-derived from the element when needed (2 VALU) instead of kept.
+        // ---- match + rank within the wave (stable), fused per element.  Match: the lanes sharing
+        // my digit (m).  Rank: every lane reads its digit's running 16-bit count, then the first lane
+        // of each digit group adds the group size with an LDS atomic -- so nothing waits on the
+        // read and the 2*KPT LDS ops pipeline (LDS serves one wave in order); the read results are
+        // consumed a group of RG elements later.  Kept per element: its 16-bit tile rank, two per
+        // VGPR; the digit is re-derived from the element where needed (2 VALU) instead of kept.
         uint32_t pk[(KPT + 1) / 2];
+        auto match_rank = [&](auto is_full) {  // body duplicated per case: the common one stays branch-free
+            constexpr bool FULL = decltype(is_full)::value;
+            constexpr int RG = KPT < RSX_RANK_GROUP ? KPT : RSX_RANK_GROUP;
 #pragma unroll
-        for (int j = 0; j < (KPT + 1) / 2; ++j) pk[j] = 0;
-        if (full) {  // branch-free body (the common case)
+            for (int j0 = 0; j0 < KPT; j0 += RG) {
+                uint32_t below[RG], word[RG], sh[RG];
 #pragma unroll
-            for (int j = 0; j < KPT; ++j) {
-                const uint64_t m = match_digit_sched(elem_digit<ES, false>(e[j], a.spec));
-                pk[j / 2] |= (mbcnt64(m) | (((uint32_t)__popcll(m) - 1u) << 6)) << (16 * (j & 1));
-                // two matches in flight hide the SGPR-write -> VALU-read wait states; more only costs VGPRs
-                if (j % RSX_MATCH_ILP == RSX_MATCH_ILP - 1) __builtin_amdgcn_sched_barrier(0);
+                for (int r = 0; r < RG; ++r) {
+                    const int j = j0 + r;
+                    uint32_t d = elem_digit<ES, false>(e[j], a.spec);
+                    uint64_t m;
+                    if constexpr (FULL) {
+                        m = match_digit_sched(d);
+                    } else {
+                        if (seg + j * WAVE >= valid) d = 255u;
+                        m = match_digit(d);
+                    }
+                    below[r] = mbcnt64(m);
+                    sh[r] = (d & 1u) * 16u;  // two 16-bit counters per LDS word
+                    word[r] = my_hist2[d >> 1];
+                    if (below[r] == 0) atomicAdd(&my_hist2[d >> 1], (uint32_t)__popcll(m) << sh[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < RG; ++r) {
+                    const int j = j0 + r;
+                    const uint32_t rank = ((word[r] >> sh[r]) & 0xFFFFu) + below[r];
+                    pk[j / 2] = (j & 1) ? (pk[j / 2] | (rank << 16)) : rank;
+                }
             }
-        } else {
-#pragma unroll
-            for (int j = 0; j < KPT; ++j) {
-                const uint32_t d = (seg + j * WAVE >= valid) ? 255u : elem_digit<ES, false>(e[j], a.spec);
-                const uint64_t m = match_digit(d);
-                pk[j / 2] |= (mbcnt64(m) | (((uint32_t)__popcll(m) - 1u) << 6)) << (16 * (j & 1));
-                if (j % RSX_MATCH_ILP == RSX_MATCH_ILP - 1) __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+        };
+        if (full) match_rank(std::true_type{});
+        else match_rank(std::false_type{});
         RSX_STAMP(1);
-
-        forget<ES, KPT>(e);
-        // ---- rank within the wave (stable).  Per round: every lane reads its digit's running
-        // count, then the first lane of each digit group adds the group size -- an atomic add, so
-        // nothing waits on the read: all 2*KPT LDS ops pipeline (LDS serves a wave in order).
-#pragma unroll
-        for (int j = 0; j < KPT; ++j) {
-            const uint32_t d = (!full && seg + j * WAVE >= valid) ? 255u : elem_digit<ES, false>(e[j], a.spec);
-            const uint32_t v = (pk[j / 2] >> (16 * (j & 1))) & 0xFFFFu;
-            const uint32_t below = v & 63u;
-            const uint32_t sh = (d & 1u) * 16u;  // two 16-bit counters per LDS word
-            const uint32_t prev = (my_hist2[d >> 1] >> sh) & 0xFFFFu;
-            if (below == 0) atomicAdd(&my_hist2[d >> 1], ((v >> 6) + 1u) << sh);
-            const uint32_t rank = prev + below;
-            pk[j / 2] = (j & 1) ? ((pk[j / 2] & 0xFFFFu) | (rank << 16)) : ((pk[j / 2] & 0xFFFF0000u) | rank);
-            if (j % 8 == 7) __builtin_amdgcn_sched_barrier(0);
-        }
         __syncthreads();
         RSX_STAMP(2);
         // from here to the end of the tile the workgroup is on short, serial phases that every
