@@ -26,7 +26,7 @@ constexpr size_t OFF_J0 = 0;
 constexpr size_t OFF_J1 = OFF_J0 + J_BYTES;
 constexpr size_t OFF_BASE = OFF_J1 + J_BYTES;       // [MAX_REGIONS][256] write cursors
 constexpr size_t OFF_TICKETS = OFF_BASE + J_BYTES;  // [MAX_REGIONS] u32
-constexpr size_t OFF_ERROR = OFF_TICKETS + 128;  // tickets[16] + roll-call words
+constexpr size_t OFF_ERROR = OFF_TICKETS + 192;  // tickets[MAX_REGIONS] + roll-call words
 constexpr size_t OFF_DBG = OFF_ERROR + 64;  // 8 diagnostic counters
 constexpr size_t AUX_BYTES = OFF_DBG + 1024;  // 16 waves x 8 diagnostic counters
 }  // namespace
@@ -145,9 +145,11 @@ RegionGeom make_geom(uint64_t n, uint32_t es) {
     static const uint64_t max_regions = [] {  // RSX_REGIONS env: tuning/diagnostics only
         const char* e = std::getenv("RSX_REGIONS");
         const uint64_t v = e ? std::strtoull(e, nullptr, 0) : 0;
-        return (v >= 1 && v <= (uint64_t)MAX_REGIONS) ? v : (uint64_t)MAX_REGIONS;
+        return (v >= 1 && v <= (uint64_t)MAX_REGIONS) ? v : 0;
     }();
-    while (((n + (1ull << k) - 1) >> k) > max_regions) ++k;
+    // narrow elements run 2 workgroups/CU and have LDS to spare for a 32-row count matrix
+    const uint64_t cap = max_regions ? max_regions : 16;  // 32 (possible for narrow elements) measured no faster
+    while (((n + (1ull << k) - 1) >> k) > cap) ++k;
     g.region_shift = k;
     g.num_regions = (uint32_t)((n + (1ull << k) - 1) >> k);
     if (g.num_regions == 0) g.num_regions = 1;
@@ -291,7 +293,7 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
     a.num_cu = (uint32_t)ctx->num_cu;
     a.dbg_cnt = reinterpret_cast<unsigned long long*>(ctx->aux + OFF_DBG);
     const size_t lds = (size_t)TILE * ES + (SWEEP_WG / WAVE) * RADIX * sizeof(uint16_t) +
-                       (NEXT ? (size_t)MAX_REGIONS * RADIX * sizeof(uint32_t) : 0) + 64;
+                       (NEXT ? (size_t)g.num_regions * RADIX * sizeof(uint32_t) : 0) + 64;
     auto kern = rsx_sweep_kernel<ES, KPT, SWEEP_WG, S, XF, NEXT>;
     static int occ = 0;  // per instantiation: resident workgroups per CU for this kernel
     if (occ == 0) {

@@ -230,7 +230,7 @@ __device__ __forceinline__ uint64_t match_digit_sched(uint32_t d) {
 // chains matters on this chip: an agent-scope status read is a memory-side round trip
 // (the 8 XCD L2s are not coherent), ~0.5 us under load, and a single chain has ~40
 // tiles in the aggregate-only state at any time -- more status traffic than key traffic.
-constexpr int MAX_REGIONS = 16;
+constexpr int MAX_REGIONS = 32;
 
 struct RegionGeom {
     uint64_t n;
@@ -470,8 +470,8 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : (ES <= 4 || KPT * ES > 64) ? 
     uint32_t* s_whist2 = reinterpret_cast<uint32_t*>(smem + TILE_BYTES);               // [NWAVE][128]: 2 x 16-bit counters per word
     uint16_t* s_whist = reinterpret_cast<uint16_t*>(s_whist2);                         // [NWAVE][256] same memory
     uint64_t* s_base = reinterpret_cast<uint64_t*>(s_whist2);                          // [256], aliases s_whist (dead by then)
-    uint32_t* s_jn = s_whist2 + NWAVE * (RADIX / 2);                                   // [MAX_REGIONS][256] (NEXT)
-    uint32_t* s_misc = s_jn + (NEXT ? MAX_REGIONS * RADIX : 0);                        // [16]
+    uint32_t* s_jn = s_whist2 + NWAVE * (RADIX / 2);                                   // [num_regions][256] (NEXT)
+    uint32_t* s_misc = s_jn + (NEXT ? a.g.num_regions * RADIX : 0);                    // [16]
     static_assert(NWAVE * RADIX * sizeof(uint16_t) >= RADIX * sizeof(uint64_t), "s_base must fit in s_whist");
 
     const E* __restrict__ src = static_cast<const E*>(a.src);
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : (ES <= 4 || KPT * ES > 64) ? 
     const uint64_t region_len = 1ull << a.g.region_shift;
 
     if (NEXT)
-        for (uint32_t i = threadIdx.x; i < MAX_REGIONS * RADIX; i += WG) s_jn[i] = 0;
+        for (uint32_t i = threadIdx.x; i < a.g.num_regions * RADIX; i += WG) s_jn[i] = 0;
 
     // ---- who sorts which tile ----------------------------------------------------------
     // Tiles of a region form a chain and must START in order (a tile only waits for lower tiles
@@ -704,16 +704,19 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : (ES <= 4 || KPT * ES > 64) ? 
         }
         __syncthreads();  // s_whist is dead from here: s_base takes its place
         RSX_STAMP(4);
-        // static mode knows its next tile: its loads are issued now (the element registers are
-        // free) and fly during the look-back and the write-out, so reads overlap writes
-        preloaded = false;
-        if (static_mode && PREFETCH && st_k < st_nt) {
+        // static mode knows its next tile: its loads are issued as soon as the element registers
+        // are free and fly during the look-back and the write-out.  The waves that do the look-back
+        // issue theirs AFTER it: memory operations return in order, so a status word requested
+        // behind 16 HBM loads would wait for all of them.
+        const bool prefetch = static_mode && PREFETCH && st_k < st_nt;
+        auto issue_next = [&]() {
             const uint64_t tb = ((uint64_t)home << a.g.region_shift) + ((uint64_t)st_k << TILE_LOG);
             const uint64_t re = ((uint64_t)(home + 1) << a.g.region_shift) < a.g.n ? ((uint64_t)(home + 1) << a.g.region_shift) : a.g.n;
             const bool fl = re - tb >= (uint64_t)TILE;
             load_tile<ES, KPT>(e, src + tb, seg, fl ? (uint32_t)TILE : (uint32_t)(re - tb), fl);
-            preloaded = true;
-        }
+        };
+        preloaded = prefetch;
+        if (prefetch && tid >= RADIX) issue_next();
 
         // ---- decoupled look-back inside the region's chain -----------------------
         if (tid < RADIX) {
@@ -752,6 +755,7 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : (ES <= 4 || KPT * ES > 64) ? 
             }
             // element index of LDS slot 0 if it belonged to this digit's run (wrap-safe in u64)
             s_base[tid] = a.region_base[reg * RADIX + tid] + excl - (uint64_t)tstart;
+            if (prefetch) issue_next();
         }
         __syncthreads();
         RSX_STAMP(5);
@@ -807,7 +811,7 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : (ES <= 4 || KPT * ES > 64) ? 
 #endif
 
     if (NEXT) {  // hand this workgroup's share of the next count matrix over
-        for (uint32_t i = threadIdx.x; i < MAX_REGIONS * RADIX; i += WG) {
+        for (uint32_t i = threadIdx.x; i < a.g.num_regions * RADIX; i += WG) {
             const uint32_t c = s_jn[i];
             if (c) atomicAdd(&a.jnext[i], (unsigned long long)c);
         }
