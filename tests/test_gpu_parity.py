@@ -253,3 +253,63 @@ def test_verify_detects_errors(rs, torch, ctx):
     v[:, 1] = torch.arange(n - 1, -1, -1, dtype=torch.int32, device="cuda")  # payload descending
     ctx.verify_device(x.data_ptr(), n, d, out.data_ptr())
     assert out[0].item() == 0 and out[2].item() == n - 1
+
+
+def test_dynamic_ticket_mode_matches(orc):
+    """The fallback tile distribution (agent-scope tickets, RSX_DEBUG bit 0x2000 forces it) must give
+    the same bytes as the static roll-call mode.  Runs in a child process: the switch is read once
+    per context from the environment."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np, torch, util
+import radix_sort_amd as rs
+from oracle import oracle
+ctx = rs.default_context(0)
+for t, n in (("u32", 3000001), ("(u64,u64)", 700001), ("f32", 1500000), ("u8", 5000000)):
+    d = rs.RadixDigits(*util.TYPES[t])
+    raw = util.make_input(t, n, "uniform" if t != "(u64,u64)" else "zipf", seed=31)
+    x = torch.from_numpy(raw.copy()).cuda()
+    rs.radix_sort(x, digits=d); ctx.check()
+    exp = oracle.sort_parallel(raw, oracle.Layout(*util.TYPES[t]), 8)
+    assert np.array_equal(x.cpu().numpy(), exp), t
+print("DYNAMIC OK")
+'''
+    env = dict(os.environ, RSX_DEBUG="0x2000")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "DYNAMIC OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_many_sorts_one_context_and_graph_capture(rs, torch, ctx):
+    """Workspace reuse across sizes/types, and stream-ordered operation: rsx_sort_device must be
+    capturable in a HIP graph once the workspace is reserved (no allocation, no sync inside)."""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for n in (5, 70000, 9, 1 << 20, 12345, 3):
+        x = torch.randint(0, 2 ** 31 - 1, (n,), generator=g, dtype=torch.int32)
+        y = x.cuda()
+        rs.radix_sort(y)
+        ctx.check()
+        assert torch.equal(y.cpu(), torch.sort(x).values)
+    n = 1 << 20
+    d = rs.PRIMITIVES["i32"]
+    ctx.reserve(n, d)
+    src = torch.randint(0, 2 ** 31 - 1, (n,), generator=g, dtype=torch.int32).cuda()
+    work = torch.empty_like(src)
+    tmp = torch.empty_like(src)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        work.copy_(src)
+        ctx.sort_device(work.data_ptr(), tmp.data_ptr(), n, d, s.cuda_stream)  # warm-up outside capture
+    s.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        work.copy_(src)
+        ctx.sort_device(work.data_ptr(), tmp.data_ptr(), n, d, torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    ctx.check()
+    assert torch.equal(work.cpu(), torch.sort(src.cpu()).values)
