@@ -175,6 +175,8 @@ def main():
     ap.add_argument("--extra", default=",".join(EXTRA_DEFAULT),
                     help="comma list of further workloads measured (3 steps each) and reported under 'extra' at N=1; '' = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", default="one", choices=["one", "per-pass"],
+                    help="multi-GPU schedule: one all-to-all (default) or one per digit pass (the reference's loop with chunk == GPU)")
     args = ap.parse_args()
 
     import torch
@@ -244,10 +246,12 @@ def main():
     def fill(i, b):
         ctx.generate_device(b.data_ptr(), n, d, gen_id(rs, gen), 0x5EED0000 + i, param, rank * n, stream)
 
+    run = (lambda b: sorter.sort_one_exchange(b, d, n_per_rank)) if args.exchange == "one" else \
+          (lambda b: sorter.sort(b, d, n_per_rank))
     wbuf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
     for i in range(args.warmup):
         fill(1000 + i, wbuf)
-        sorter.sort(wbuf, d, n_per_rank)
+        run(wbuf)
     for i in range(pool):
         fill(i, bufs[i])
     torch.cuda.synchronize()
@@ -255,7 +259,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        sorter.sort(bufs[i], d, n_per_rank)
+        run(bufs[i])
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -276,7 +280,10 @@ def main():
             "vs_baseline": None, "dtype": "u%d" % (8 * d.key_bytes) if t[0] in "u(" else t, "data": "synthetic",
             "config": {"workload": f"{args.workload} per GPU x {world}: {desc}", "n_keys": total,
                        "n_keys_per_gpu": n, "elem_bytes": d.elem_bytes, "passes": d.key_bytes, "radix_bits": 8,
-                       "generator": gen, "exchange": "per-pass all-gather(256 x u64) + all-to-all-v (RCCL)"},
+                       "generator": gen,
+                       "exchange": ("local sort + 256-way splitter search (1 all-reduce per digit) + ONE all-to-all-v + "
+                                    "local sort (RCCL)") if args.exchange == "one" else
+                                   "per-pass all-gather(256 x u64) + all-to-all-v (RCCL)"},
             "roofline": {"bound": "hbm", "achieved": d.key_bytes * 2 * total * d.elem_bytes / ms / 1e6,
                          "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
                          "frac": d.key_bytes * 2 * total * d.elem_bytes / ms / 1e6 / (HBM_PEAK_GBPS * world),

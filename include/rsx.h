@@ -125,6 +125,13 @@ int rsx_segmented_copy_device(rsx_ctx *ctx, const void *d_src, void *d_dst, uint
                               const uint64_t *d_src_off, const uint64_t *d_dst_off,
                               const uint64_t *d_len, uint32_t nseg, void *stream);
 
+/* Order-preserving signed 64-bit form of every key (key_bytes <= 8): the mapped
+ * key of radix_digits.rs zero-extended with its top bit flipped, so that signed
+ * comparison of d_keys[i] equals the sort order.  The multi-GPU driver uses it to
+ * find its splitters by binary search in locally sorted slices.  d_keys: n int64. */
+int rsx_extract_keys_device(rsx_ctx *ctx, const void *d_src, size_t n, const rsx_layout *layout,
+                            int64_t *d_keys, void *stream);
+
 /* -- harness helpers (input generation / verification on device) --------- */
 enum {
     RSX_GEN_UNIFORM = 0, /* key = splitmix64(seed, i) truncated        (distr.rs:40-52 KeyUniform shape) */

@@ -699,6 +699,28 @@ int rsx_segmented_copy_device(rsx_ctx* ctx, const void* d_src, void* d_dst, uint
     return RSX_ERR_HIP;
 }
 
+int rsx_extract_keys_device(rsx_ctx* ctx, const void* d_src, size_t n, const rsx_layout* L, int64_t* d_keys,
+                            void* stream) try {
+    if (!ctx) return RSX_ERR_ARG;
+    if (!layout_ok(L)) return fail(ctx, RSX_ERR_ARG, "invalid rsx_layout");
+    if (L->key_bytes > 8) return fail(ctx, RSX_ERR_UNSUPPORTED, "keys wider than 8 bytes have no 64-bit form");
+    if (n == 0) return RSX_OK;
+    if (!d_src || !d_keys) return fail(ctx, RSX_ERR_ARG, "null pointer");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    uint64_t blocks = (n + 255) / 256;
+    const uint64_t cap = (uint64_t)ctx->num_cu * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(rsx_extract_keys_kernel, dim3((uint32_t)blocks), dim3(256), 0, st,
+                       static_cast<const uint8_t*>(d_src), (uint64_t)n, L->elem_bytes, L->key_offset, L->key_bytes,
+                       L->key_kind, reinterpret_cast<long long*>(d_keys));
+    RSX_HIP(hipGetLastError());
+    return RSX_OK;
+} catch (...) {
+    return RSX_ERR_HIP;
+}
+
 int rsx_generate_device(rsx_ctx* ctx, void* d_data, size_t n, const rsx_layout* L, int gen, uint64_t seed,
                         double param, uint64_t index_base, void* stream) try {
     if (!ctx) return RSX_ERR_ARG;

@@ -919,6 +919,22 @@ __device__ __forceinline__ void mapped_key(const uint8_t* e, uint32_t key_offset
     }
 }
 
+// Order-preserving signed 64-bit form of every key (keys of up to 8 bytes): the mapped key
+// (radix_digits.rs) zero-extended, with the top bit flipped so that signed comparison of the
+// outputs equals the sort order.  Used by the multi-GPU driver to locate its splitters by
+// binary search in locally sorted slices.
+__global__ __launch_bounds__(256) void rsx_extract_keys_kernel(const uint8_t* __restrict__ data, uint64_t n,
+                                                               uint32_t elem_bytes, uint32_t key_offset,
+                                                               uint32_t key_bytes, uint32_t kind,
+                                                               long long* __restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint64_t lo, hi;
+        mapped_key(data + i * elem_bytes, key_offset, key_bytes, kind, lo, hi);
+        out[i] = (long long)(lo ^ 0x8000000000000000ull);
+    }
+}
+
 __global__ __launch_bounds__(256) void rsx_verify_kernel(const uint8_t* __restrict__ data, uint64_t n,
                                                          uint32_t elem_bytes, uint32_t key_offset, uint32_t key_bytes,
                                                          uint32_t kind, uint64_t* __restrict__ out) {

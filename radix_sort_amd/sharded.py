@@ -56,6 +56,18 @@ class HipBackend:
     def to_device_i64(self, a: np.ndarray):
         return self.torch.from_numpy(a.astype(np.int64)).to(self.device, non_blocking=False)
 
+    def sort(self, x, tmp, n: int, d: RadixDigits):
+        """Full local sort (rsx_sort_device), in place in x."""
+        s = self.torch.cuda.current_stream().cuda_stream
+        self.ctx.sort_device(x.data_ptr(), tmp.data_ptr(), n, d, s)
+
+    def mapped_keys(self, x, n: int, d: RadixDigits):
+        """int64 tensor, signed order == sort order (rsx_extract_keys_device)."""
+        k = self.torch.empty(n, dtype=self.torch.int64, device=self.device)
+        s = self.torch.cuda.current_stream().cuda_stream
+        self.ctx.extract_keys_device(x.data_ptr(), n, d, k.data_ptr(), s)
+        return k
+
     def finish(self):
         self.ctx.check(self.torch.cuda.current_stream().cuda_stream)
 
@@ -100,8 +112,23 @@ def exchange_plan(H: np.ndarray, n_per_rank: np.ndarray, rank: int):
     return send_counts, recv_counts, segs
 
 
+def _signed64(u: np.ndarray) -> np.ndarray:
+    """unsigned 64-bit key values -> the signed form used by mapped_keys (top bit flipped)."""
+    return (u.astype(np.uint64) ^ np.uint64(1 << 63)).view(np.int64)
+
+
 class ShardedRadixSort:
-    """`radix_sort` over a slice-per-rank array.  All ranks call `sort` collectively."""
+    """`radix_sort` over a slice-per-rank array.  All ranks call `sort` collectively.
+
+    Two schedules with the same (unique) result:
+      * `sort`              one bucket exchange per pass -- the reference's loop with chunk == rank;
+      * `sort_one_exchange` sort locally, find the exact splitters of the destination slices by a
+                            256-way search over the key digits (one small all-reduce per digit),
+                            exchange ONCE, sort locally again (the received chunks arrive ordered by
+                            source rank, so a stable local sort reproduces the global stable order).
+    xGMI moves (G-1)/G of every slice per exchange at a small fraction of HBM speed, so the number
+    of exchanges, not the local passes, decides multi-GPU throughput.
+    """
 
     def __init__(self, group=None, backend=None):
         import torch.distributed as dist
@@ -121,17 +148,101 @@ class ShardedRadixSort:
             b = self._bufs[name] = self.backend.empty_bytes(nbytes)
         return b[:nbytes]
 
+    def _gather_counts(self, n_local: int, device) -> List[int]:
+        import torch
+        dev = torch.device("cpu") if self.host_staged else device
+        t = torch.tensor([n_local], dtype=torch.int64, device=dev)
+        allt = [torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(allt, t, group=self.group)
+        return [int(a.item()) for a in allt]
+
+    def _all_reduce_sum(self, a: np.ndarray, device) -> np.ndarray:
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64))
+        if not self.host_staged:
+            t = t.to(device)
+        self.dist.all_reduce(t, group=self.group)
+        return t.cpu().numpy()
+
+    def sort_one_exchange(self, x, d: RadixDigits, n_per_rank: Optional[List[int]] = None):
+        """Same contract as `sort`; one all-to-all instead of one per digit.  Keys wider than
+        8 bytes fall back to `sort`."""
+        if d.key_bytes > 8:
+            return self.sort(x, d, n_per_rank)
+        import torch
+        dist, be = self.dist, self.backend
+        es, G = d.elem_bytes, self.world
+        n_local = x.numel() // es
+        if n_per_rank is None:
+            n_per_rank = self._gather_counts(n_local, x.device)
+        n_per_rank = np.asarray(n_per_rank, dtype=np.int64)
+        assert n_per_rank[self.rank] == n_local
+        bounds = np.concatenate(([0], np.cumsum(n_per_rank)))
+        tmp = self._buf("part", n_local * es)
+        recv = self._buf("recv", n_local * es)
+        # 1. local sort (stable)
+        if n_local > 1:
+            be.sort(x, tmp, n_local, d)
+        keys = be.mapped_keys(x, n_local, d)  # sorted ascending (signed order == key order)
+        # 2. exact splitters: for every interior boundary T_h the key K_h with
+        #    global_less(K_h) <= T_h < global_less_or_equal(K_h), found digit by digit (256-way)
+        targets = bounds[1:-1]  # G-1 boundaries
+        nb = len(targets)
+        bits = 8 * d.key_bytes
+        prefix = np.zeros(nb, dtype=np.uint64)
+        for digit in range(d.key_bytes - 1, -1, -1):
+            shift = np.uint64(8 * digit)
+            cand = prefix[:, None] | (np.arange(256, dtype=np.uint64)[None, :] << shift)  # [nb][256]
+            less = torch.searchsorted(keys, torch.from_numpy(_signed64(cand.reshape(-1))).to(keys.device))
+            gl = self._all_reduce_sum(less.cpu().numpy(), x.device).reshape(nb, 256)
+            # largest candidate whose global "less" count does not exceed the target
+            j = (gl <= targets[:, None]).sum(axis=1) - 1  # gl[:,0] counts keys < prefix: always <= target
+            prefix |= j.astype(np.uint64) << shift
+        maxkey = np.uint64((1 << bits) - 1) if bits < 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
+        k_lo = torch.from_numpy(_signed64(prefix)).to(keys.device)
+        less_me = torch.searchsorted(keys, k_lo).cpu().numpy().astype(np.int64)  # elements < K_h on this rank
+        leq_me = torch.searchsorted(keys, k_lo, right=True).cpu().numpy().astype(np.int64)  # elements <= K_h
+        mine = np.stack([less_me, leq_me]).astype(np.int64)  # [2][nb]
+        allm = [torch.zeros(2 * nb, dtype=torch.int64) for _ in range(G)]
+        src = torch.from_numpy(mine.reshape(-1))
+        if self.host_staged:
+            dist.all_gather(allm, src, group=self.group)
+        else:
+            allm = [a.to(x.device) for a in allm]
+            dist.all_gather(allm, src.to(x.device), group=self.group)
+        M = torch.stack([a.cpu() for a in allm]).numpy().reshape(G, 2, nb)
+        less, eq = M[:, 0, :], M[:, 1, :] - M[:, 0, :]  # [G][nb]
+        # ties on K_h are dealt out in rank order (stability: lower source rank first)
+        need = targets - less.sum(axis=0)  # elements equal to K_h that go below boundary h
+        before = np.cumsum(eq, axis=0) - eq
+        take = np.clip(need[None, :] - before, 0, eq)
+        split = np.concatenate([np.zeros((G, 1), np.int64), less + take, n_per_rank[:, None]], axis=1)  # [G][G+1]
+        send_counts = np.diff(split[self.rank])  # to each destination
+        recv_counts = split[:, self.rank + 1] - split[:, self.rank]  # from each source
+        assert send_counts.sum() == n_local and recv_counts.sum() == n_local, (send_counts, recv_counts)
+        del keys
+        # 3. the one exchange
+        if self.host_staged and x.is_cuda:
+            rc = torch.empty(n_local * es, dtype=torch.uint8)
+            dist.all_to_all_single(rc, x.cpu(), output_split_sizes=(recv_counts * es).tolist(),
+                                   input_split_sizes=(send_counts * es).tolist(), group=self.group)
+            recv.copy_(rc)
+        else:
+            dist.all_to_all_single(recv, x, output_split_sizes=(recv_counts * es).tolist(),
+                                   input_split_sizes=(send_counts * es).tolist(), group=self.group)
+        # 4. chunks arrive ordered by source rank, each sorted: a stable sort merges them
+        x.copy_(recv)
+        if n_local > 1:
+            be.sort(x, tmp, n_local, d)
+        be.finish()
+
     def sort(self, x, d: RadixDigits, n_per_rank: Optional[List[int]] = None):
         """x: this rank's slice as a contiguous uint8 tensor (n_local * elem_bytes).  In place."""
         dist, be = self.dist, self.backend
         es = d.elem_bytes
         n_local = x.numel() // es
         if n_per_rank is None:
-            import torch
-            t = torch.tensor([n_local], dtype=torch.int64, device=x.device)
-            allt = [torch.zeros_like(t) for _ in range(self.world)]
-            dist.all_gather(allt, t, group=self.group)
-            n_per_rank = [int(a.item()) for a in allt]
+            n_per_rank = self._gather_counts(n_local, x.device)
         n_per_rank = np.asarray(n_per_rank, dtype=np.int64)
         assert n_per_rank[self.rank] == n_local
         part = self._buf("part", n_local * es)

@@ -51,11 +51,23 @@ class OracleBackend:
     def to_device_i64(self, a):
         return self.torch.from_numpy(a.astype(np.int64))
 
+    def sort(self, x, tmp, n, d):
+        lay = self.orc.Layout(d.elem_bytes, d.key_offset, d.key_bytes, d.key_kind)
+        x.numpy()[: n * d.elem_bytes] = self.orc.sort_parallel(x.numpy()[: n * d.elem_bytes].copy(), lay, 2)
+
+    def mapped_keys(self, x, n, d):
+        lay = self.orc.Layout(d.elem_bytes, d.key_offset, d.key_bytes, d.key_kind)
+        cols = self.orc.numpy_mapped_key_columns(x.numpy()[: n * d.elem_bytes], lay)
+        pad = np.zeros((n, 8), dtype=np.uint8)
+        pad[:, : d.key_bytes] = cols
+        u = pad.view("<u8").reshape(n)
+        return self.torch.from_numpy((u ^ np.uint64(1 << 63)).view(np.int64).copy())
+
     def finish(self):
         pass
 
 
-def _worker(rank, world, port, tname, dist_name, sizes, outdir):
+def _worker(rank, world, port, tname, dist_name, sizes, outdir, one_exchange=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -72,7 +84,8 @@ def _worker(rank, world, port, tname, dist_name, sizes, outdir):
         off = sum(sizes[:rank])
         mine = full[off * d.elem_bytes:(off + sizes[rank]) * d.elem_bytes].copy()
         x = torch.from_numpy(mine)
-        ShardedRadixSort(backend=OracleBackend()).sort(x, d, n_per_rank=list(sizes))
+        sorter = ShardedRadixSort(backend=OracleBackend())
+        (sorter.sort_one_exchange if one_exchange else sorter.sort)(x, d, n_per_rank=list(sizes))
         np.save(os.path.join(outdir, f"out{rank}.npy"), x.numpy())
     finally:
         dist.destroy_process_group()
@@ -89,6 +102,25 @@ def test_sharded_gloo_matches_single_sort(orc, tmp_path, world, tname, dist_name
     import torch.multiprocessing as mp
     port = _free_port()
     mp.spawn(_worker, args=(world, port, tname, dist_name, sizes, str(tmp_path)), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / f"out{r}.npy") for r in range(world)])
+    lay = orc.Layout(*util.TYPES[tname])
+    full = util.make_input(tname, sum(sizes), dist_name, seed=77)
+    assert np.array_equal(got, orc.sort_parallel(full, lay, 3))
+
+
+@pytest.mark.parametrize("world,tname,dist_name,sizes", [
+    (2, "u32", "uniform", (5000, 5000)),
+    (2, "(u64,u64)", "zipf", (4097, 4097)),
+    (2, "f32", "uniform", (3000, 1234)),
+    (3, "(u32,u32)", "two", (1000, 0, 2500)),   # heavy ties straddling both boundaries, an empty slice
+    (3, "i16", "equal", (700, 900, 800)),       # every key equal: all splitting is by tie order
+    (2, "f64", "uniform", (2048, 2049)),
+    (2, "u128", "uniform", (1500, 1500)),       # wide keys: falls back to the per-pass schedule
+])
+def test_one_exchange_gloo_matches_single_sort(orc, tmp_path, world, tname, dist_name, sizes):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, tname, dist_name, sizes, str(tmp_path), True), nprocs=world, join=True)
     got = np.concatenate([np.load(tmp_path / f"out{r}.npy") for r in range(world)])
     lay = orc.Layout(*util.TYPES[tname])
     full = util.make_input(tname, sum(sizes), dist_name, seed=77)
@@ -120,7 +152,7 @@ def test_exchange_plan_properties():
 
 
 # ---- GPU: the real HIP local steps under the same exchange, 2 ranks sharing one MI355X ----------
-def _gpu_worker(rank, world, port, tname, dist_name, sizes, outdir):
+def _gpu_worker(rank, world, port, tname, dist_name, sizes, outdir, one_exchange=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -136,7 +168,8 @@ def _gpu_worker(rank, world, port, tname, dist_name, sizes, outdir):
         full = util.make_input(tname, sum(sizes), dist_name, seed=78)
         off = sum(sizes[:rank])
         x = torch.from_numpy(full[off * d.elem_bytes:(off + sizes[rank]) * d.elem_bytes].copy()).cuda()
-        ShardedRadixSort().sort(x, d, n_per_rank=list(sizes))  # product backend: HIP through the C-ABI
+        sorter = ShardedRadixSort()  # product backend: HIP through the C-ABI
+        (sorter.sort_one_exchange if one_exchange else sorter.sort)(x, d, n_per_rank=list(sizes))
         np.save(os.path.join(outdir, f"out{rank}.npy"), x.cpu().numpy())
     finally:
         dist.destroy_process_group()
@@ -152,6 +185,24 @@ def test_sharded_hip_two_ranks_one_gpu(orc, tmp_path, tname, dist_name, sizes):
     import torch.multiprocessing as mp
     port = _free_port()
     mp.spawn(_gpu_worker, args=(2, port, tname, dist_name, sizes, str(tmp_path)), nprocs=2, join=True)
+    got = np.concatenate([np.load(tmp_path / f"out{r}.npy") for r in range(2)])
+    lay = orc.Layout(*util.TYPES[tname])
+    full = util.make_input(tname, sum(sizes), dist_name, seed=78)
+    assert np.array_equal(got, orc.sort_parallel(full, lay, 4))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tname,dist_name,sizes", [
+    ("u32", "uniform", (300000, 300000)),
+    ("(u64,u64)", "zipf", (150001, 99999)),
+    ("f64", "uniform", (70000, 1)),
+    ("(u32,u32)", "two", (200000, 123457)),
+    ("i16", "equal", (65536, 70000)),
+])
+def test_one_exchange_hip_two_ranks_one_gpu(orc, tmp_path, tname, dist_name, sizes):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_gpu_worker, args=(2, port, tname, dist_name, sizes, str(tmp_path), True), nprocs=2, join=True)
     got = np.concatenate([np.load(tmp_path / f"out{r}.npy") for r in range(2)])
     lay = orc.Layout(*util.TYPES[tname])
     full = util.make_input(tname, sum(sizes), dist_name, seed=78)
