@@ -292,7 +292,7 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
     a.stagger = ctx->stagger;
     a.num_cu = (uint32_t)ctx->num_cu;
     a.dbg_cnt = reinterpret_cast<unsigned long long*>(ctx->aux + OFF_DBG);
-    const size_t lds = (size_t)TILE * ES + (SWEEP_WG / WAVE) * RADIX * sizeof(uint16_t) +
+    const size_t lds = (size_t)TILE * ES + (SWEEP_WG / WAVE) * RADIX * ((ES <= 4 && KPT >= 16 && SWEEP_WG <= 512) ? sizeof(uint32_t) : sizeof(uint16_t)) +
                        (NEXT ? (size_t)g.num_regions * RADIX * sizeof(uint32_t) : 0) + 64;
     auto kern = rsx_sweep_kernel<ES, KPT, SWEEP_WG, S, XF, NEXT>;
     static int occ = 0;  // per instantiation: resident workgroups per CU for this kernel

@@ -184,38 +184,38 @@ __device__ __forceinline__ uint64_t match_digit_sched(uint32_t d) {
         "v_bfe_i32 %2, %5, 0, 1\n\t"
         "v_bfe_i32 %3, %5, 1, 1\n\t"
         "v_cmp_ne_u32_e64 vcc, 0, %2\n\t"
-        "v_cmp_ne_u32_e64 s[96:97], 0, %3\n\t"
+        "v_cmp_ne_u32_e64 s[76:77], 0, %3\n\t"
         "v_bfe_i32 %4, %5, 2, 1\n\t"
-        "v_cmp_ne_u32_e64 s[98:99], 0, %4\n\t"
+        "v_cmp_ne_u32_e64 s[78:79], 0, %4\n\t"
         "v_bitop3_b32 %0, -1, vcc_lo, %2 bitop3:0x90\n\t"
         "v_bitop3_b32 %1, -1, vcc_hi, %2 bitop3:0x90\n\t"
         "v_bfe_i32 %2, %5, 3, 1\n\t"
         "v_cmp_ne_u32_e64 vcc, 0, %2\n\t"
-        "v_bitop3_b32 %0, %0, s96, %3 bitop3:0x90\n\t"
-        "v_bitop3_b32 %1, %1, s97, %3 bitop3:0x90\n\t"
+        "v_bitop3_b32 %0, %0, s76, %3 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, s77, %3 bitop3:0x90\n\t"
         "v_bfe_i32 %3, %5, 4, 1\n\t"
-        "v_cmp_ne_u32_e64 s[96:97], 0, %3\n\t"
-        "v_bitop3_b32 %0, %0, s98, %4 bitop3:0x90\n\t"
-        "v_bitop3_b32 %1, %1, s99, %4 bitop3:0x90\n\t"
+        "v_cmp_ne_u32_e64 s[76:77], 0, %3\n\t"
+        "v_bitop3_b32 %0, %0, s78, %4 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, s79, %4 bitop3:0x90\n\t"
         "v_bfe_i32 %4, %5, 5, 1\n\t"
-        "v_cmp_ne_u32_e64 s[98:99], 0, %4\n\t"
+        "v_cmp_ne_u32_e64 s[78:79], 0, %4\n\t"
         "v_bitop3_b32 %0, %0, vcc_lo, %2 bitop3:0x90\n\t"
         "v_bitop3_b32 %1, %1, vcc_hi, %2 bitop3:0x90\n\t"
         "v_bfe_i32 %2, %5, 6, 1\n\t"
         "v_cmp_ne_u32_e64 vcc, 0, %2\n\t"
-        "v_bitop3_b32 %0, %0, s96, %3 bitop3:0x90\n\t"
-        "v_bitop3_b32 %1, %1, s97, %3 bitop3:0x90\n\t"
+        "v_bitop3_b32 %0, %0, s76, %3 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, s77, %3 bitop3:0x90\n\t"
         "v_bfe_i32 %3, %5, 7, 1\n\t"
-        "v_cmp_ne_u32_e64 s[96:97], 0, %3\n\t"
-        "v_bitop3_b32 %0, %0, s98, %4 bitop3:0x90\n\t"
-        "v_bitop3_b32 %1, %1, s99, %4 bitop3:0x90\n\t"
+        "v_cmp_ne_u32_e64 s[76:77], 0, %3\n\t"
+        "v_bitop3_b32 %0, %0, s78, %4 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, s79, %4 bitop3:0x90\n\t"
         "v_bitop3_b32 %0, %0, vcc_lo, %2 bitop3:0x90\n\t"
         "v_bitop3_b32 %1, %1, vcc_hi, %2 bitop3:0x90\n\t"
-        "v_bitop3_b32 %0, %0, s96, %3 bitop3:0x90\n\t"
-        "v_bitop3_b32 %1, %1, s97, %3 bitop3:0x90"
+        "v_bitop3_b32 %0, %0, s76, %3 bitop3:0x90\n\t"
+        "v_bitop3_b32 %1, %1, s77, %3 bitop3:0x90"
         : "=&v"(lo), "=&v"(hi), "=&v"(t0), "=&v"(t1), "=&v"(t2)
         : "v"(d)
-        : "vcc", "s96", "s97", "s98", "s99");
+        : "vcc", "s76", "s77", "s78", "s79");
     return ((uint64_t)hi << 32) | lo;
 }
 
@@ -390,6 +390,9 @@ struct SweepArgs {
 #ifndef RSX_MATCH_ILP
 #define RSX_MATCH_ILP 2
 #endif
+#ifndef RSX_NUM_SGPR
+#define RSX_NUM_SGPR 102
+#endif
 #ifndef RSX_RANK_GROUP
 #define RSX_RANK_GROUP 4
 #endif
@@ -452,7 +455,10 @@ template <int ES, int KPT, int WG, typename S, int XF, bool NEXT>
 // VGPR budget: 4-byte (and narrower) keys carry 16 elements per thread and need ~104 VGPRs; capping
 // them at 80 (3 workgroups/CU) spills, and the spills cost more than the third workgroup buys
 // (measured: 0.82 -> 0.68 ms per 256M-key pass at 2 workgroups/CU without spills).
-__global__ __launch_bounds__(WG, (WG == 1024 ? 8 : (ES <= 4 || KPT * ES > 64) ? 4 : RSX_MINW)) void rsx_sweep_kernel(const SweepArgs a) {
+// SGPR budget: the hardware admits waves by SGPRs too (800 per SIMD in blocks of 16, +16 per wave):
+// above 80 SGPRs a kernel cannot have 8 waves per SIMD however few VGPRs it uses.
+__global__ __launch_bounds__(WG, (WG == 1024 ? 8 : KPT * (ES < 4 ? 4 : ES) >= 64 ? 4 : RSX_MINW))
+__attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const SweepArgs a) {
     constexpr int NWAVE = WG / WAVE;
     constexpr int TILE = WG * KPT;
     constexpr int TILE_LOG = __builtin_ctz(TILE);
@@ -467,12 +473,16 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : (ES <= 4 || KPT * ES > 64) ? 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr size_t TILE_BYTES = (size_t)TILE * sizeof(E);
     E* s_elems = reinterpret_cast<E*>(smem);                                           // [TILE]
-    uint32_t* s_whist2 = reinterpret_cast<uint32_t*>(smem + TILE_BYTES);               // [NWAVE][128]: 2 x 16-bit counters per word
-    uint16_t* s_whist = reinterpret_cast<uint16_t*>(s_whist2);                         // [NWAVE][256] same memory
+    // per-wave digit counters: 32-bit where LDS allows (narrow elements run 2 workgroups/CU), else
+    // two 16-bit counters per word (saves 4 KiB, costs ~6 VALU per element for shifts and masks)
+    constexpr bool WIDE_CNT = ES <= 4 && KPT >= 16 && WG <= 512;  // where the workgroup runs 2 per CU anyway
+    using Cnt = typename std::conditional<WIDE_CNT, uint32_t, uint16_t>::type;
+    uint32_t* s_whist2 = reinterpret_cast<uint32_t*>(smem + TILE_BYTES);               // the counters as LDS words
+    Cnt* s_whist = reinterpret_cast<Cnt*>(s_whist2);                                   // [NWAVE][256]
     uint64_t* s_base = reinterpret_cast<uint64_t*>(s_whist2);                          // [256], aliases s_whist (dead by then)
-    uint32_t* s_jn = s_whist2 + NWAVE * (RADIX / 2);                                   // [num_regions][256] (NEXT)
+    uint32_t* s_jn = s_whist2 + NWAVE * RADIX * sizeof(Cnt) / 4;                       // [num_regions][256] (NEXT)
     uint32_t* s_misc = s_jn + (NEXT ? a.g.num_regions * RADIX : 0);                    // [16]
-    static_assert(NWAVE * RADIX * sizeof(uint16_t) >= RADIX * sizeof(uint64_t), "s_base must fit in s_whist");
+    static_assert(NWAVE * RADIX * sizeof(Cnt) >= RADIX * sizeof(uint64_t), "s_base must fit in s_whist");
 
     const E* __restrict__ src = static_cast<const E*>(a.src);
     S* status = static_cast<S*>(a.status);
@@ -517,6 +527,7 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : (ES <= 4 || KPT * ES > 64) ? 
     }
     __syncthreads();
     const bool static_mode = __builtin_amdgcn_readfirstlane(s_misc[3]) == 1u;
+    if ((a.dbg & 0x100u) && threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&a.dbg_cnt[5], static_mode ? 1ull : 0ull);
     // workgroup index, XCD-major (blocks are dealt round-robin over the 8 XCDs): the workgroups of
     // one chain then share an XCD, which makes their status hand-offs faster -- never a
     // correctness matter
@@ -572,9 +583,11 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : (ES <= 4 || KPT * ES > 64) ? 
         asm volatile("" : "+v"(tid));
         const uint32_t lane = tid & 63;
         const uint32_t wave = tid >> 6;
-        uint32_t* my_hist2 = s_whist2 + wave * (RADIX / 2);
-        uint16_t* my_hist = s_whist + wave * RADIX;
-        reinterpret_cast<uint64_t*>(my_hist2)[lane] = 0;  // each wave clears its 256 16-bit counters
+        uint32_t* my_hist2 = s_whist2 + wave * (RADIX * sizeof(Cnt) / 4);
+        Cnt* my_hist = s_whist + wave * RADIX;
+#pragma unroll
+        for (int i = 0; i < (int)(RADIX * sizeof(Cnt) / 8 / WAVE); ++i)  // each wave clears its 256 counters
+            reinterpret_cast<uint64_t*>(my_hist2)[i * WAVE + lane] = 0;
         // dynamic mode: the ticket is drawn when the tile starts, so ticket order == start order inside
         // a chain.  (Drawing it earlier hides the atomic's round trip but makes a workgroup sit on a
         // ticket while the tiles behind it in the chain already wait for its aggregate: measured slower.)
@@ -637,14 +650,20 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : (ES <= 4 || KPT * ES > 64) ? 
                         m = match_digit(d);
                     }
                     below[r] = mbcnt64(m);
-                    sh[r] = (d & 1u) * 16u;  // two 16-bit counters per LDS word
-                    word[r] = my_hist2[d >> 1];
-                    if (below[r] == 0) atomicAdd(&my_hist2[d >> 1], (uint32_t)__popcll(m) << sh[r]);
+                    if constexpr (WIDE_CNT) {
+                        sh[r] = 0;
+                        word[r] = my_hist2[d];
+                        if (below[r] == 0) atomicAdd(&my_hist2[d], (uint32_t)__popcll(m));
+                    } else {
+                        sh[r] = (d & 1u) * 16u;  // two 16-bit counters per LDS word
+                        word[r] = my_hist2[d >> 1];
+                        if (below[r] == 0) atomicAdd(&my_hist2[d >> 1], (uint32_t)__popcll(m) << sh[r]);
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < RG; ++r) {
                     const int j = j0 + r;
-                    const uint32_t rank = ((word[r] >> sh[r]) & 0xFFFFu) + below[r];
+                    const uint32_t rank = (WIDE_CNT ? word[r] : ((word[r] >> sh[r]) & 0xFFFFu)) + below[r];
                     pk[j / 2] = (j & 1) ? (pk[j / 2] | (rank << 16)) : rank;
                 }
             }
@@ -688,7 +707,7 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? 8 : (ES <= 4 || KPT * ES > 64) ? 
 #pragma unroll
             for (int w = 0; w < NWAVE; ++w) {  // counts are re-read rather than kept in 8 VGPRs across the barrier
                 const uint32_t c = s_whist[w * RADIX + tid];
-                s_whist[w * RADIX + tid] = (uint16_t)run;
+                s_whist[w * RADIX + tid] = (Cnt)run;
                 run += c;
             }
         }
