@@ -132,6 +132,19 @@ int rsx_segmented_copy_device(rsx_ctx *ctx, const void *d_src, void *d_dst, uint
 int rsx_extract_keys_device(rsx_ctx *ctx, const void *d_src, size_t n, const rsx_layout *layout,
                             int64_t *d_keys, void *stream);
 
+/* -- multi-GPU from one process ------------------------------------------- */
+/* Sorts the concatenation slice 0 | slice 1 | ... | slice ndev-1 as ONE array,
+ * stably and in place: slice g keeps its length n_per_dev[g] and ends up
+ * holding elements [sum(n_per_dev[..g]), +n_per_dev[g]) of the sorted whole --
+ * bit-identical to rsx_sort_device on the concatenation.  "Chunk per thread"
+ * of mod.rs:66-70,90-168 becomes "slice per GPU".  ctxs[g] is bound to the
+ * device that holds d_slices[g] and d_tmps[g] (scratch of the same size as the
+ * slice); one context per slice, several may share a device.  Blocking; uses
+ * the NULL stream of every device; data crosses devices once (peer copies over
+ * xGMI), between two local sorts.  Errors are reported on ctxs[0]. */
+int rsx_sort_sharded(rsx_ctx *const *ctxs, uint32_t ndev, void *const *d_slices, void *const *d_tmps,
+                     const size_t *n_per_dev, const rsx_layout *layout);
+
 /* -- harness helpers (input generation / verification on device) --------- */
 enum {
     RSX_GEN_UNIFORM = 0, /* key = splitmix64(seed, i) truncated        (distr.rs:40-52 KeyUniform shape) */

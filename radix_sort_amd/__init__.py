@@ -5,10 +5,11 @@ src/radix_sort/mod.rs:18-20,61-176); `RadixDigits` mirrors the key trait
 (src/radix_sort/radix_digits.rs:1-5).  All compute runs in the HIP library
 librsx.so behind the C-ABI of include/rsx.h; there is no CPU fallback.
 """
-from .api import (PRIMITIVES, Context, RadixDigits, default_context, digits_of, radix_sort, tuple_of)
+from .api import (PRIMITIVES, Context, RadixDigits, default_context, digits_of, radix_sort, radix_sort_sharded,
+                  tuple_of)
 from ._lib import (GEN_CONSTANT, GEN_REVERSED, GEN_SORTED, GEN_STEP, GEN_UNIFORM, GEN_ZIPF, KEY_FLOAT, KEY_SIGNED,
                    KEY_UNSIGNED, Layout, RsxError)
 
-__all__ = ["radix_sort", "RadixDigits", "PRIMITIVES", "tuple_of", "digits_of", "Context", "default_context",
+__all__ = ["radix_sort", "radix_sort_sharded", "RadixDigits", "PRIMITIVES", "tuple_of", "digits_of", "Context", "default_context",
            "Layout", "RsxError", "KEY_UNSIGNED", "KEY_SIGNED", "KEY_FLOAT", "GEN_UNIFORM", "GEN_ZIPF", "GEN_STEP",
            "GEN_SORTED", "GEN_REVERSED", "GEN_CONSTANT"]

@@ -15,7 +15,7 @@ from __future__ import annotations
 import ctypes
 import threading
 from dataclasses import dataclass
-from typing import Optional
+from typing import Optional, Sequence
 
 import numpy as np
 
@@ -257,4 +257,39 @@ def radix_sort(x, digits: Optional[RadixDigits] = None, tmp=None, ctx: Optional[
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
         c.sort_device(x.data_ptr(), tmp.data_ptr(), n, d, stream)
+    return None
+
+
+def radix_sort_sharded(slices: Sequence, digits: RadixDigits, ctxs: Optional[Sequence[Context]] = None, tmps=None):
+    """rsx_sort_sharded: sorts the concatenation of `slices` (contiguous GPU tensors, one per
+    context, possibly on different devices) as ONE array, stably and in place -- every slice
+    keeps its length.  The single-process multi-GPU form of `<[T]>::radix_sort` with "chunk per
+    thread" (mod.rs:66-70) read as "slice per GPU".  Blocking."""
+    import torch
+    G = len(slices)
+    if G == 0:
+        return None
+    if ctxs is None:
+        ctxs = [Context(t.device.index if t.device.index is not None else torch.cuda.current_device()) for t in slices]
+    if len(ctxs) != G:
+        raise ValueError("one context per slice")
+    if tmps is None:
+        tmps = [torch.empty_like(t) for t in slices]
+    ns = []
+    for t, u in zip(slices, tmps):
+        if not (t.is_cuda and t.is_contiguous() and u.is_cuda and u.is_contiguous() and u.device == t.device):
+            raise ValueError("slices and tmps must be contiguous GPU tensors, pairwise on the same device")
+        nbytes = t.numel() * t.element_size()
+        if nbytes % digits.elem_bytes or u.numel() * u.element_size() < nbytes:
+            raise ValueError("slice size is not a multiple of elem_bytes, or tmp too small")
+        ns.append(nbytes // digits.elem_bytes)
+    for t in slices:  # the library works on the NULL stream of each device
+        torch.cuda.synchronize(t.device)
+    L = ctxs[0]._L
+    hs = (ctypes.c_void_p * G)(*[c._h for c in ctxs])
+    ps = (ctypes.c_void_p * G)(*[t.data_ptr() for t in slices])
+    ts = (ctypes.c_void_p * G)(*[t.data_ptr() for t in tmps])
+    nn = (ctypes.c_size_t * G)(*ns)
+    lay = digits.layout()
+    ctxs[0]._check(L.rsx_sort_sharded(hs, G, ps, ts, nn, ctypes.byref(lay)))
     return None

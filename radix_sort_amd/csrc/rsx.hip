@@ -721,6 +721,184 @@ int rsx_extract_keys_device(rsx_ctx* ctx, const void* d_src, size_t n, const rsx
     return RSX_ERR_HIP;
 }
 
+// ---- multi-GPU, one process: one exchange between two local sorts ------------------------------
+// The G slices are "chunks" in the sense of mod.rs:66-70; the result is what the reference would
+// produce on their concatenation.  Schedule: (1) every device sorts its slice; (2) the G-1 slice
+// boundaries of the sorted whole are located exactly -- boundary h is the key K_h with
+// less(K_h) <= T_h < less_or_equal(K_h) over all slices, found digit by digit (256 candidates per
+// step, counted by binary search in every sorted slice), ties on K_h dealt out in slice order;
+// (3) each device pushes the G ranges of its slice to their owners over xGMI, ordered by source
+// slice at the receiver; (4) a second stable local sort merges the G sorted runs.  Stability: equal
+// keys stay in (source slice, local index) order through (3), and (4) is stable.
+int rsx_sort_sharded(rsx_ctx* const* ctxs, uint32_t ndev, void* const* d_slices, void* const* d_tmps,
+                     const size_t* n_per_dev, const rsx_layout* L) try {
+    if (!ctxs || ndev == 0 || !ctxs[0]) return RSX_ERR_ARG;
+    rsx_ctx* ctx = ctxs[0];  // carries the error text
+    if (!d_slices || !d_tmps || !n_per_dev) return fail(ctx, RSX_ERR_ARG, "null table");
+    const uint32_t G = ndev;
+    if (G > 64) return fail(ctx, RSX_ERR_ARG, "more than 64 slices");
+    for (uint32_t g = 0; g < G; ++g) {
+        if (!ctxs[g]) return fail(ctx, RSX_ERR_ARG, "null context in table");
+        int rc = check_common(ctxs[g], L);
+        if (rc) return rc == RSX_ERR_ARG ? fail(ctx, rc, "invalid rsx_layout") : fail(ctx, rc, "element size has no device kernel");
+        if (n_per_dev[g] && (!d_slices[g] || !d_tmps[g])) return fail(ctx, RSX_ERR_ARG, "null device pointer");
+        for (uint32_t h = 0; h < g; ++h)
+            if (ctxs[h] == ctxs[g]) return fail(ctx, RSX_ERR_ARG, "one context per slice");
+    }
+    const size_t es = L->elem_bytes;
+    // (1) local sorts, all devices at once
+    auto sort_all = [&]() -> int {
+        for (uint32_t g = 0; g < G; ++g) {
+            int rc = rsx_sort_device(ctxs[g], d_slices[g], d_tmps[g], n_per_dev[g], L, nullptr);
+            if (rc) return g ? fail(ctx, rc, rsx_last_error(ctxs[g])) : rc;
+        }
+        for (uint32_t g = 0; g < G; ++g) {
+            int rc = rsx_ctx_check(ctxs[g], nullptr);
+            if (rc) return g ? fail(ctx, rc, rsx_last_error(ctxs[g])) : rc;
+        }
+        return RSX_OK;
+    };
+    int rc = sort_all();
+    if (rc || G == 1) return rc;
+
+    std::vector<uint64_t> bounds(G + 1, 0);
+    for (uint32_t g = 0; g < G; ++g) bounds[g + 1] = bounds[g] + n_per_dev[g];
+    const uint32_t nb = G - 1;
+    const uint32_t nq_max = nb * RADIX;
+
+    // per-device query / answer buffers
+    struct Scratch {
+        rsx_ctx* c = nullptr;
+        uint64_t* q = nullptr;
+        uint64_t* out = nullptr;
+        ~Scratch() {
+            if (!c) return;
+            DeviceGuard g(c->device);
+            if (q) (void)hipFree(q);
+            if (out) (void)hipFree(out);
+        }
+    };
+    std::vector<Scratch> scr(G);
+    for (uint32_t g = 0; g < G; ++g) {
+        DeviceGuard dg(ctxs[g]->device);
+        if (!dg.ok) return fail(ctx, RSX_ERR_NODEVICE, "hipSetDevice failed");
+        scr[g].c = ctxs[g];
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&scr[g].q), (size_t)nq_max * 2 * sizeof(uint64_t));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&scr[g].out), (size_t)nq_max * 2 * sizeof(uint64_t));
+        if (e != hipSuccess) return fail(ctx, RSX_ERR_NOMEM, "splitter scratch hipMalloc", e);
+    }
+    // counts[g][0..nq) = elements < Q on slice g, counts[g][nq..2nq) = elements <= Q
+    std::vector<std::vector<uint64_t>> counts(G, std::vector<uint64_t>((size_t)nq_max * 2));
+    auto ask = [&](const std::vector<uint64_t>& q, uint32_t nq) -> int {
+        for (uint32_t g = 0; g < G; ++g) {
+            std::lock_guard<std::mutex> lk(ctxs[g]->mu);
+            DeviceGuard dg(ctxs[g]->device);
+            RSX_HIP(hipMemcpyAsync(scr[g].q, q.data(), (size_t)nq * 2 * sizeof(uint64_t), hipMemcpyHostToDevice, nullptr));
+            hipLaunchKernelGGL(rsx_bounds_kernel, dim3((nq + 255) / 256), dim3(256), 0, nullptr,
+                               static_cast<const uint8_t*>(d_slices[g]), (uint64_t)n_per_dev[g], L->elem_bytes,
+                               L->key_offset, L->key_bytes, L->key_kind, scr[g].q, nq, scr[g].out);
+            RSX_HIP(hipGetLastError());
+        }
+        for (uint32_t g = 0; g < G; ++g) {
+            std::lock_guard<std::mutex> lk(ctxs[g]->mu);
+            DeviceGuard dg(ctxs[g]->device);
+            RSX_HIP(hipMemcpy(counts[g].data(), scr[g].out, (size_t)nq * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        }
+        return RSX_OK;
+    };
+
+    // (2) splitters, most significant digit first
+    std::vector<uint64_t> pre_lo(nb, 0), pre_hi(nb, 0), q((size_t)nq_max * 2);
+    for (int digit = (int)L->key_bytes - 1; digit >= 0; --digit) {
+        for (uint32_t b = 0; b < nb; ++b)
+            for (uint32_t j = 0; j < RADIX; ++j) {
+                uint64_t lo = pre_lo[b], hi = pre_hi[b];
+                if (digit < 8) lo |= (uint64_t)j << (8 * digit);
+                else hi |= (uint64_t)j << (8 * (digit - 8));
+                q[2 * ((size_t)b * RADIX + j)] = lo;
+                q[2 * ((size_t)b * RADIX + j) + 1] = hi;
+            }
+        rc = ask(q, nq_max);
+        if (rc) return rc;
+        for (uint32_t b = 0; b < nb; ++b) {
+            // largest candidate whose global "less" count does not exceed the boundary
+            uint32_t pick = 0;
+            for (uint32_t j = 0; j < RADIX; ++j) {
+                uint64_t less = 0;
+                for (uint32_t g = 0; g < G; ++g) less += counts[g][(size_t)b * RADIX + j];
+                if (less <= bounds[b + 1]) pick = j;  // monotone in j
+            }
+            if (digit < 8) pre_lo[b] |= (uint64_t)pick << (8 * digit);
+            else pre_hi[b] |= (uint64_t)pick << (8 * (digit - 8));
+        }
+    }
+    for (uint32_t b = 0; b < nb; ++b) {
+        q[2 * b] = pre_lo[b];
+        q[2 * b + 1] = pre_hi[b];
+    }
+    rc = ask(q, nb);
+    if (rc) return rc;
+    // split[g][h] = first element of slice g that goes to owner h
+    std::vector<std::vector<uint64_t>> split(G, std::vector<uint64_t>(G + 1, 0));
+    for (uint32_t g = 0; g < G; ++g) split[g][G] = n_per_dev[g];
+    for (uint32_t b = 0; b < nb; ++b) {
+        uint64_t less_total = 0;
+        for (uint32_t g = 0; g < G; ++g) less_total += counts[g][b];
+        uint64_t need = bounds[b + 1] - less_total;  // elements equal to K_b that go below the boundary
+        for (uint32_t g = 0; g < G; ++g) {            // ties: lower slice first (stability)
+            const uint64_t less = counts[g][b], eq = counts[g][nb + b] - less;
+            const uint64_t take = need < eq ? need : eq;
+            split[g][b + 1] = less + take;
+            need -= take;
+        }
+        if (need != 0) return fail(ctx, RSX_ERR_INTERNAL, "splitter search inconsistent");
+    }
+    for (uint32_t h = 0; h < G; ++h) {
+        uint64_t got = 0;
+        for (uint32_t g = 0; g < G; ++g) {
+            if (split[g][h + 1] < split[g][h]) return fail(ctx, RSX_ERR_INTERNAL, "splitters not monotone");
+            got += split[g][h + 1] - split[g][h];
+        }
+        if (got != n_per_dev[h]) return fail(ctx, RSX_ERR_INTERNAL, "exchange plan does not fill a slice");
+    }
+
+    // (3) the exchange: slice g pushes its range for owner h into h's scratch, behind the ranges
+    // of the slices before it.  d_tmps is idle (all local sorts were synchronised above).
+    for (uint32_t g = 0; g < G; ++g) {
+        std::lock_guard<std::mutex> lk(ctxs[g]->mu);
+        DeviceGuard dg(ctxs[g]->device);
+        for (uint32_t k = 0; k < G; ++k) {
+            const uint32_t h = (g + k) % G;  // start with myself, then round the ring: spreads the links
+            const uint64_t cnt = split[g][h + 1] - split[g][h];
+            if (cnt == 0) continue;
+            uint64_t at = 0;
+            for (uint32_t p = 0; p < g; ++p) at += split[p][h + 1] - split[p][h];
+            const char* src = static_cast<const char*>(d_slices[g]) + split[g][h] * es;
+            char* dst = static_cast<char*>(d_tmps[h]) + at * es;
+            if (ctxs[h]->device == ctxs[g]->device) {
+                RSX_HIP(hipMemcpyAsync(dst, src, cnt * es, hipMemcpyDeviceToDevice, nullptr));
+            } else {
+                // direct xGMI writes where the topology allows; the copy works either way
+                if (hipDeviceEnablePeerAccess(ctxs[h]->device, 0) != hipSuccess) (void)hipGetLastError();
+                RSX_HIP(hipMemcpyPeerAsync(dst, ctxs[h]->device, src, ctxs[g]->device, cnt * es, nullptr));
+            }
+        }
+    }
+    for (uint32_t g = 0; g < G; ++g) {
+        DeviceGuard dg(ctxs[g]->device);
+        RSX_HIP(hipStreamSynchronize(nullptr));
+    }
+    // (4) G sorted runs per slice -> one: a stable sort of the received slice
+    for (uint32_t g = 0; g < G; ++g) {
+        if (n_per_dev[g] == 0) continue;
+        DeviceGuard dg(ctxs[g]->device);
+        RSX_HIP(hipMemcpyAsync(d_slices[g], d_tmps[g], n_per_dev[g] * es, hipMemcpyDeviceToDevice, nullptr));
+    }
+    return sort_all();
+} catch (...) {
+    return RSX_ERR_NOMEM;
+}
+
 int rsx_generate_device(rsx_ctx* ctx, void* d_data, size_t n, const rsx_layout* L, int gen, uint64_t seed,
                         double param, uint64_t index_base, void* stream) try {
     if (!ctx) return RSX_ERR_ARG;

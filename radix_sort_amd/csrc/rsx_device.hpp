@@ -621,6 +621,10 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         // ---- load + digit + match: independent -> ILP ------------
         __builtin_amdgcn_s_setprio(0);
         if (!preloaded) load_tile<ES, KPT>(e, src + tile_base, seg, valid, full);
+#ifdef RSX_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // diagnostic build: split load wait from match
+        RSX_STAMP(7);
+#endif
         if constexpr ((XF & 1) != 0) {  // first pass of a sort: keys become order-preserving unsigned
 #pragma unroll
             for (int j = 0; j < KPT; ++j) key_map<ES, false>(e[j], a.xf);
@@ -740,7 +744,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         // ---- decoupled look-back inside the region's chain -----------------------
         if (tid < RADIX) {
             uint64_t excl = 0;
-            if (kt > 0 && !(a.dbg & 1u)) {
+            if (kt > 0) {
                 // one predecessor per hop: examining several per round trip was measured slower
                 // (the extra status reads cost more than the saved latency)
                 uint64_t row = stat_row - RADIX;  // predecessor in the chain
@@ -952,6 +956,36 @@ __global__ __launch_bounds__(256) void rsx_extract_keys_kernel(const uint8_t* __
         mapped_key(data + i * elem_bytes, key_offset, key_bytes, kind, lo, hi);
         out[i] = (long long)(lo ^ 0x8000000000000000ull);
     }
+}
+
+// Lower and upper bound of 128-bit mapped-key queries in a slice that is sorted by mapped key:
+// out[qi] = number of elements with key < Q, out[nq + qi] = number with key <= Q.  One thread per
+// query; the multi-GPU splitter search (rsx_sort_sharded) asks a few hundred at a time.
+__global__ __launch_bounds__(256) void rsx_bounds_kernel(const uint8_t* __restrict__ data, uint64_t n,
+                                                         uint32_t elem_bytes, uint32_t key_offset, uint32_t key_bytes,
+                                                         uint32_t kind, const uint64_t* __restrict__ q, uint32_t nq,
+                                                         uint64_t* __restrict__ out) {
+    const uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= nq) return;
+    const uint64_t qlo = q[2 * qi], qhi = q[2 * qi + 1];
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {  // first element with key >= Q
+        const uint64_t mid = lo + (hi - lo) / 2;
+        uint64_t klo, khi;
+        mapped_key(data + mid * elem_bytes, key_offset, key_bytes, kind, klo, khi);
+        if (khi < qhi || (khi == qhi && klo < qlo)) lo = mid + 1;
+        else hi = mid;
+    }
+    out[qi] = lo;
+    hi = n;
+    while (lo < hi) {  // first element with key > Q
+        const uint64_t mid = lo + (hi - lo) / 2;
+        uint64_t klo, khi;
+        mapped_key(data + mid * elem_bytes, key_offset, key_bytes, kind, klo, khi);
+        if (khi < qhi || (khi == qhi && klo <= qlo)) lo = mid + 1;
+        else hi = mid;
+    }
+    out[nq + qi] = lo;
 }
 
 __global__ __launch_bounds__(256) void rsx_verify_kernel(const uint8_t* __restrict__ data, uint64_t n,

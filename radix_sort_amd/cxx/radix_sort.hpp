@@ -142,4 +142,23 @@ void radix_sort_device(T* d_data, T* d_tmp, size_t n, void* stream = nullptr, Co
     ctx.check(rsx_sort_device(ctx.get(), d_data, d_tmp, n, &L, stream), "rsx_sort_device");
 }
 
+// Multi-GPU, one process: slice g lives on the device of ctxs[g]; the concatenation of the slices
+// is sorted as one array (slice = the reference's "chunk", mod.rs:66-70).  Blocking.
+template <typename T>
+void radix_sort_sharded(const std::vector<Context*>& ctxs, const std::vector<T*>& d_slices,
+                        const std::vector<T*>& d_tmps, const std::vector<size_t>& n_per_dev) {
+    if (ctxs.empty() || ctxs.size() != d_slices.size() || ctxs.size() != d_tmps.size() || ctxs.size() != n_per_dev.size())
+        throw std::invalid_argument("radix_sort_sharded: one context, slice, tmp and length per device");
+    const rsx_layout L = RadixDigits<T>::layout();
+    std::vector<rsx_ctx*> h;
+    std::vector<void*> s, t;
+    for (size_t g = 0; g < ctxs.size(); ++g) {
+        h.push_back(ctxs[g]->get());
+        s.push_back(d_slices[g]);
+        t.push_back(d_tmps[g]);
+    }
+    ctxs[0]->check(rsx_sort_sharded(h.data(), (uint32_t)h.size(), s.data(), t.data(), n_per_dev.data(), &L),
+                   "rsx_sort_sharded");
+}
+
 }  // namespace rsx

@@ -33,6 +33,9 @@ extern "C" {
     pub fn rsx_sort_host(ctx: *mut RsxCtx, data: *mut c_void, n: usize, layout: *const RsxLayout) -> c_int;
     pub fn rsx_sort_device(ctx: *mut RsxCtx, d_data: *mut c_void, d_tmp: *mut c_void, n: usize,
                            layout: *const RsxLayout, stream: *mut c_void) -> c_int;
+    pub fn rsx_sort_sharded(ctxs: *const *mut RsxCtx, ndev: u32, d_slices: *const *mut c_void,
+                            d_tmps: *const *mut c_void, n_per_dev: *const usize,
+                            layout: *const RsxLayout) -> c_int;
     pub fn rsx_strerror(status: c_int) -> *const c_char;
 }
 

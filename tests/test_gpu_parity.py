@@ -313,3 +313,43 @@ def test_many_sorts_one_context_and_graph_capture(rs, torch, ctx):
     torch.cuda.synchronize()
     ctx.check()
     assert torch.equal(work.cpu(), torch.sort(src.cpu()).values)
+
+
+# ---- rsx_sort_sharded: single-process multi-slice sort (slices share the one GPU of the test box) ----
+SHARD_SPLITS = [
+    [5000, 5000], [1, 9999], [0, 7000, 3000], [3333, 0, 3333, 3334], [12345], [100003, 50001, 70007],
+    [2, 1, 0, 1], [8192, 8192, 8192, 8192, 8192, 8192, 8192, 8192],
+]
+
+
+@pytest.mark.parametrize("t", ["u8", "u32", "i32", "f32", "u64", "f64", "i128", "(u64,u64)", "(u8,[u8;7])",
+                               "(pay32+u32)", "(u32,[u8;8])"])
+def test_sharded_single_process(rs, torch, orc, t):
+    d = _digits(rs, t)
+    lay = orc.Layout(*util.TYPES[t])
+    es = util.TYPES[t][0]
+    for si, split in enumerate(SHARD_SPLITS):
+        for dist in ("uniform", "two", "zipf"):
+            n = sum(split)
+            raw = util.make_input(t, n, dist, seed=4242 + si)
+            want = orc.sort_parallel(raw, lay, 4)
+            flat = raw.reshape(-1).view(np.uint8)
+            offs = np.concatenate(([0], np.cumsum(split))) * es
+            slices = [torch.from_numpy(flat[offs[g]:offs[g + 1]].copy()).cuda() for g in range(len(split))]
+            ctxs = [rs.Context(torch.cuda.current_device()) for _ in split]
+            rs.radix_sort_sharded(slices, d, ctxs=ctxs)
+            got = np.concatenate([s.cpu().numpy() for s in slices]) if n else np.zeros(0, np.uint8)
+            assert np.array_equal(got, want.reshape(-1).view(np.uint8)), (t, split, dist)
+            for c in ctxs:
+                c.close()
+
+
+def test_sharded_argument_errors(rs, torch):
+    d = rs.PRIMITIVES["u32"]
+    c = rs.Context(torch.cuda.current_device())
+    a = torch.zeros(16, dtype=torch.int32, device="cuda")
+    b = torch.zeros(16, dtype=torch.int32, device="cuda")
+    with pytest.raises(rs.RsxError):  # the same context twice
+        rs.radix_sort_sharded([a, b], d, ctxs=[c, c])
+    with pytest.raises(ValueError):
+        rs.radix_sort_sharded([a, b], d, ctxs=[c])

@@ -20,4 +20,5 @@ for it in range(2):
     for w in range(8):
         o = out[w*8:(w+1)*8]
         tot = sum(o[k] for k in range(7))
-        print(f"wave {w}: " + " | ".join(f"{names[k][:14]} {o[k]/ntile:6.0f}" for k in range(7)), f"| total {tot/ntile:.0f}")
+        tot += o[7]
+        print(f"wave {w}: load-wait {o[7]/ntile:6.0f} | " + " | ".join(f"{names[k][:14]} {o[k]/ntile:6.0f}" for k in range(7)), f"| total {tot/ntile:.0f}")
