@@ -44,7 +44,8 @@ _LIB = None
 
 
 def lib_path() -> str:
-    return _build.LIB
+    # RSX_LIBRARY: another build of the same library (A/B timing of build-time knobs)
+    return os.environ.get("RSX_LIBRARY") or _build.LIB
 
 
 def load():

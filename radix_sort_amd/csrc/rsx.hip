@@ -326,6 +326,12 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
         }
         a.wg_first[NR] = (uint16_t)grid;
         for (uint32_t r = NR + 1; r <= (uint32_t)MAX_REGIONS; ++r) a.wg_first[r] = (uint16_t)grid;
+        // regions whose workgroups fall into one class of the kernel's XCD-major numbering
+        // (class = index / (grid/8) = blockIdx % 8): candidates for L2-local status words
+        a.local_mask = 0;
+        if (grid % 8 == 0 && !(ctx->dbg & 0x4000u))
+            for (uint32_t r = 0; r < NR; ++r)
+                if (a.wg_first[r] / (grid / 8) == (a.wg_first[r + 1] - 1u) / (grid / 8)) a.local_mask |= 1u << r;
     }
     if (ctx->dbg & 0x200u) std::fprintf(stderr, "[rsx] sweep ES=%d NEXT=%d occ=%d grid=%llu lds=%zu tiles=%llu regions=%u\n", ES, (int)NEXT, occ, (unsigned long long)grid, lds, (unsigned long long)total_tiles, g.num_regions);
     LaunchTimer lt(ctx, RSX_PROF_SWEEP, st);

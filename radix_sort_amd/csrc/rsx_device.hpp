@@ -353,6 +353,7 @@ struct SweepArgs {
     uint32_t* tickets;            // [MAX_REGIONS] per-region tile counters, zeroed; [MAX_REGIONS], [MAX_REGIONS+1]:
                                   // arrival count and mode word of the start-up roll call, zeroed
     uint16_t wg_first[MAX_REGIONS + 1];  // static mode: region r is served by workgroups [wg_first[r], wg_first[r+1])
+    uint32_t local_mask;          // static mode: regions whose workgroups all sit in one residue class of blockIdx % 8
     unsigned long long* jnext;    // [MAX_REGIONS][256] next pass's count matrix (accumulated), or null
     uint32_t* error;              // set non-zero if a bounded spin gave up
     DigitSpec spec;               // this pass's digit
@@ -396,8 +397,14 @@ struct SweepArgs {
 #ifndef RSX_RANK_GROUP
 #define RSX_RANK_GROUP 4
 #endif
+#ifndef RSX_DPP_SCAN
+#define RSX_DPP_SCAN 2  // 0 off, 1 on, 2 = where measured faster (elements of <= 4 bytes)
+#endif
+#ifndef RSX_PRIO_BAL
+#define RSX_PRIO_BAL 0
+#endif
 #ifndef RSX_PREFETCH_ALL
-#define RSX_PREFETCH_ALL 0
+#define RSX_PREFETCH_ALL 3  // 0 off, 1 before/after the look-back, 2 behind it, 3 = 2 where measured faster (>= 12-byte elements)
 #endif
 
 // Makes the compiler forget what it knows about the element registers: digits derived from them
@@ -421,6 +428,33 @@ __device__ __forceinline__ void forget(Elem<ES> (&e)[KPT]) {
 // Skewed keys put many lanes of a wave on one bin, and same-address LDS atomics serialise; when
 // at least a quarter of the wave shares the first lane's bin the wave matches its bins instead
 // (12 bits: region | digit) and one lane per bin adds the group size.
+// Inclusive scan over the 64 lanes of a wave in 6 DPP steps (no LDS traffic, unlike __shfl_up):
+// row_shr 1,2,4,8 scan each row of 16; row_bcast:15 adds a row's total to the next odd row,
+// row_bcast:31 adds the lower half's total to the upper half.
+template <bool DPP>
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+  if constexpr (DPP) {
+    auto step = [](uint32_t v, auto ctrl, auto rows) {
+        return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, decltype(rows)::value, 0xf, false);
+    };
+    x = step(x, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});
+    x = step(x, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});
+    x = step(x, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});
+    x = step(x, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});
+    x = step(x, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});
+    x = step(x, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
+    return x;
+  } else {
+    const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o);
+        if (lane >= (uint32_t)o) x += y;
+    }
+    return x;
+  }
+}
+
 __device__ __forceinline__ void count_next(uint32_t* s_jn, uint32_t bin) {
     const uint32_t b0 = __builtin_amdgcn_readfirstlane(bin);
     const uint64_t same = __ballot(bin == b0);
@@ -464,7 +498,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
     constexpr int TILE_LOG = __builtin_ctz(TILE);
     // next-tile prefetch keeps the element registers live through the write-out: only where that fits
     // the VGPR budget without spilling (u32 x 16 keys does not at 80 VGPRs, and is VALU-bound anyway)
-    constexpr bool PREFETCH = RSX_PREFETCH_ALL != 0;  // measured slower on u32 and u64: off
+    constexpr bool PREFETCH = RSX_PREFETCH_ALL != 0 && (RSX_PREFETCH_ALL != 3 || ES >= 12);
     static_assert((TILE & (TILE - 1)) == 0, "tile size must be a power of two (regions are whole tiles)");
     static_assert(WG >= RADIX, "need one thread per digit");
     static_assert(TILE <= 65536 / 2, "wave counters are 16 bit");
@@ -510,24 +544,34 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         if (!(a.dbg & 0x2000u)) {
             uint32_t* arrive = a.tickets + MAX_REGIONS;
             uint32_t* modew = a.tickets + MAX_REGIONS + 1;
-            __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // The same word also collects whether workgroups sit where the XCD-major numbering below
+            // assumes (XCC id == blockIdx % 8): low half = arrivals, high half = workgroups that do not.
+            uint32_t xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            const bool placed = (gridDim.x % 8u == 0u) && ((xcc & 0xFu) == blockIdx.x % 8u);
+            __hip_atomic_fetch_add(arrive, placed ? 1u : 0x10001u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long t0 = __builtin_amdgcn_s_memtime();
             uint32_t seen = 0;
             do {
                 seen = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (seen == gridDim.x) break;
+                if ((seen & 0xFFFFu) == gridDim.x) break;
                 __builtin_amdgcn_s_sleep(4);
             } while (__builtin_amdgcn_s_memtime() - t0 < 200000ull);
             uint32_t expected = 0;
-            __hip_atomic_compare_exchange_strong(modew, &expected, seen == gridDim.x ? 1u : 2u, __ATOMIC_RELAXED,
-                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t verdict = (seen & 0xFFFFu) != gridDim.x ? 2u : (seen == gridDim.x ? 3u : 1u);
+            __hip_atomic_compare_exchange_strong(modew, &expected, verdict, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
             mode = __hip_atomic_load(modew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         s_misc[3] = mode;
     }
     __syncthreads();
-    const bool static_mode = __builtin_amdgcn_readfirstlane(s_misc[3]) == 1u;
-    if ((a.dbg & 0x100u) && threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&a.dbg_cnt[5], static_mode ? 1ull : 0ull);
+    const uint32_t mode = __builtin_amdgcn_readfirstlane(s_misc[3]);  // 1/3 static, 2 dynamic, 3 = placement verified
+    const bool static_mode = mode != 2u;
+    if ((a.dbg & 0x100u) && threadIdx.x == 0 && blockIdx.x == 0) {
+        atomicAdd(&a.dbg_cnt[5], static_mode ? 1ull : 0ull);
+        atomicAdd(&a.dbg_cnt[6], mode == 3u ? 1ull : 0ull);
+    }
     // workgroup index, XCD-major (blocks are dealt round-robin over the 8 XCDs): the workgroups of
     // one chain then share an XCD, which makes their status hand-offs faster -- never a
     // correctness matter
@@ -542,6 +586,16 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         const uint64_t rlen = (a.g.n - rbeg) < region_len ? (a.g.n - rbeg) : region_len;
         st_nt = (uint32_t)((rlen + TILE - 1) >> TILE_LOG);
     }
+    // A chain whose workgroups were all verified on ONE XCD shares one L2: its status words can then
+    // be plain stores that stay in that L2 (an agent-scope store writes through to memory and the
+    // next agent-scope load of the line misses: 750 vs 510 cycles per hand-off, scratch/pingpong.hip).
+    // The loads stay agent-scope (they bypass the reader's L1 and hit the L2).  Speed only: without
+    // the proof every status store is agent-scope.
+    const bool local_chain = mode == 3u && ((a.local_mask >> home) & 1u) != 0u && !(a.dbg & 0x8000u);
+    auto publish = [&](S* p, S v) {
+        if (local_chain) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     uint32_t rr = home;  // dynamic mode: region the next ticket is drawn from
     uint32_t alive = NR;            // regions not yet seen exhausted
     uint32_t exhausted = 0;         // bitmask of exhausted regions
@@ -619,7 +673,8 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         const uint32_t seg = wave * (WAVE * KPT) + lane;
 
         // ---- load + digit + match: independent -> ILP ------------
-        __builtin_amdgcn_s_setprio(0);
+        if (RSX_PRIO_BAL && wave >= NWAVE / 2) __builtin_amdgcn_s_setprio(1);  // the younger half otherwise trails the older
+        else __builtin_amdgcn_s_setprio(0);
         if (!preloaded) load_tile<ES, KPT>(e, src + tile_base, seg, valid, full);
 #ifdef RSX_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // diagnostic build: split load wait from match
@@ -688,17 +743,12 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
             for (int w = 0; w < NWAVE; ++w) tcount += s_whist[w * RADIX + tid];
             const uint32_t real = (tid == 255) ? tcount - pad : tcount;
             const S flag = (kt == 0) ? (S)2 : (S)1;  // first tile of a chain: aggregate == inclusive
-            __hip_atomic_store(&status[stat_row + tid], (flag << Status<S>::SHIFT) | (S)real, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+            publish(&status[stat_row + tid], (flag << Status<S>::SHIFT) | (S)real);
         }
         // exclusive scan of tcount over the 256 digits -> start of each digit's run in the tile
         uint32_t incl = tcount;
         if (tid < RADIX) {
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t y = __shfl_up(incl, o);
-                if (lane >= (uint32_t)o) incl += y;
-            }
+            incl = wave_incl_scan<(RSX_DPP_SCAN == 1 || (RSX_DPP_SCAN == 2 && ES <= 4))>(incl);
             if (lane == 63) s_misc[12 + wave] = incl;
         }
         __syncthreads();
@@ -739,7 +789,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
             load_tile<ES, KPT>(e, src + tb, seg, fl ? (uint32_t)TILE : (uint32_t)(re - tb), fl);
         };
         preloaded = prefetch;
-        if (prefetch && tid >= RADIX) issue_next();
+        if (prefetch && RSX_PREFETCH_ALL == 1 && tid >= RADIX) issue_next();
 
         // ---- decoupled look-back inside the region's chain -----------------------
         if (tid < RADIX) {
@@ -772,16 +822,15 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                     atomicMax(&a.dbg_cnt[4], (unsigned long long)hops);
                 }
                 const uint32_t real = (tid == 255) ? tcount - pad : tcount;
-                __hip_atomic_store(&status[stat_row + tid],
-                                   ((S)2 << Status<S>::SHIFT) | (S)((excl + real) & (uint64_t)Status<S>::MASK),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                publish(&status[stat_row + tid], ((S)2 << Status<S>::SHIFT) | (S)((excl + real) & (uint64_t)Status<S>::MASK));
             }
             // element index of LDS slot 0 if it belonged to this digit's run (wrap-safe in u64)
             s_base[tid] = a.region_base[reg * RADIX + tid] + excl - (uint64_t)tstart;
-            if (prefetch) issue_next();
+            if (prefetch && RSX_PREFETCH_ALL == 1) issue_next();
         }
         __syncthreads();
         RSX_STAMP(5);
+        if (prefetch && RSX_PREFETCH_ALL >= 2) issue_next();  // all waves, behind the look-back: flies during the write-out
 
         // ---- write runs: consecutive threads -> consecutive addresses within a run;
         // ---- count the NEXT pass's digit per destination region on the way out

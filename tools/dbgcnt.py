@@ -16,5 +16,5 @@ for it in range(3):
     rs.radix_sort(x, digits=d, tmp=tmp)
     L.rsx_debug_counters(ctx._h, out, 1)
     t, hops, spins, depth, mx = out[0], out[1], out[2], out[3], out[4]
-    print(f"static-mode launches {out[5]} of 4;", end=" ")
+    print(f"static-mode launches {out[5]} of 4, placement-verified {out[6]};", end=" ")
     print(f"tiles {t} hops/tile {hops/t:.2f} stall-spins/tile {spins/t:.2f} depth(tiles)/tile {depth/t:.2f} max hops {mx}")
