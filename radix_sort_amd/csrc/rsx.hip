@@ -43,6 +43,8 @@ struct rsx_ctx {
     size_t host_bytes = 0;
     int num_cu = 256;
     uint32_t stagger = 1;  // RSX_STAGGER env (tuning)
+    bool rank_atomic = false;  // LDS atomic ordering self-test passed (set when the workspace is first made)
+    uint32_t hot_lanes = 8;    // RSX_HOT env (tuning)
     uint32_t dbg = 0;  // RSX_DEBUG env: timing-only ablation switches for the sweep kernel
     // per-launch HIP-event timing (rsx_ctx_profile)
     bool prof = false;
@@ -199,6 +201,14 @@ int ensure_workspace(rsx_ctx* ctx, size_t n, const rsx_layout* L) {
         RSX_HIP(hipMalloc(&p, AUX_BYTES));
         ctx->aux = static_cast<char*>(p);
         RSX_HIP(hipMemset(ctx->aux, 0, AUX_BYTES));
+        // may the sweep rank by returned LDS atomics on this device?  (see rsx_lds_order_kernel)
+        uint32_t* flag = error_of(ctx) + 1;
+        hipLaunchKernelGGL(rsx_lds_order_kernel, dim3(64), dim3(512), 0, nullptr, flag);
+        RSX_HIP(hipGetLastError());
+        uint32_t failed = 1;
+        RSX_HIP(hipMemcpy(&failed, flag, sizeof failed, hipMemcpyDeviceToHost));
+        ctx->rank_atomic = failed == 0 && !(ctx->dbg & 0x10000u);
+        if (ctx->dbg & 0x200u) std::fprintf(stderr, "[rsx] LDS atomic order self-test %s\n", failed ? "FAILED: ballots only" : "passed");
     }
     const size_t need = status_bytes_for(n, L->elem_bytes);
     if (need > ctx->status_bytes) {
@@ -289,10 +299,12 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
     a.spec.flip = a.next.flip = 0;  // the sweep sees mapped keys: plain digits
     a.xf = make_xform(L);
     a.dbg = ctx->dbg;
+    a.rank_atomic = ctx->rank_atomic ? 1u : 0u;
+    a.hot_lanes = (ctx->dbg & 0x20000u) ? 65u : ctx->hot_lanes;  // 0x20000: atomics whatever the skew (timing only)
     a.stagger = ctx->stagger;
     a.num_cu = (uint32_t)ctx->num_cu;
     a.dbg_cnt = reinterpret_cast<unsigned long long*>(ctx->aux + OFF_DBG);
-    const size_t lds = (size_t)TILE * ES + (SWEEP_WG / WAVE) * RADIX * ((ES <= 4 && KPT >= 16 && SWEEP_WG <= 512) ? sizeof(uint32_t) : sizeof(uint16_t)) +
+    const size_t lds = (size_t)TILE * ES + (SWEEP_WG / WAVE) * RADIX * ((RSX_WIDE_CNT && ES <= 4 && KPT >= 16 && SWEEP_WG <= 512) ? sizeof(uint32_t) : sizeof(uint16_t)) +
                        (NEXT ? (size_t)g.num_regions * RADIX * sizeof(uint32_t) : 0) + 64;
     auto kern = rsx_sweep_kernel<ES, KPT, SWEEP_WG, S, XF, NEXT>;
     static int occ = 0;  // per instantiation: resident workgroups per CU for this kernel
@@ -452,6 +464,7 @@ int rsx_ctx_create(int device, rsx_ctx** out) try {
     if (!ctx) return RSX_ERR_NOMEM;
     ctx->device = device;
     if (const char* dbg = std::getenv("RSX_DEBUG")) ctx->dbg = (uint32_t)std::strtoul(dbg, nullptr, 0);
+    if (const char* h = std::getenv("RSX_HOT")) ctx->hot_lanes = (uint32_t)std::strtoul(h, nullptr, 0);
     if (const char* sg = std::getenv("RSX_STAGGER")) ctx->stagger = (uint32_t)std::strtoul(sg, nullptr, 0);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {

@@ -353,6 +353,8 @@ struct SweepArgs {
     uint32_t* tickets;            // [MAX_REGIONS] per-region tile counters, zeroed; [MAX_REGIONS], [MAX_REGIONS+1]:
                                   // arrival count and mode word of the start-up roll call, zeroed
     uint16_t wg_first[MAX_REGIONS + 1];  // static mode: region r is served by workgroups [wg_first[r], wg_first[r+1])
+    uint32_t rank_atomic;         // 1: ranks may come from returned LDS atomics (ordering self-test passed)
+    uint32_t hot_lanes;           // a digit shared by this many lanes of round 0 sends the tile down the ballot path
     uint32_t local_mask;          // static mode: regions whose workgroups all sit in one residue class of blockIdx % 8
     unsigned long long* jnext;    // [MAX_REGIONS][256] next pass's count matrix (accumulated), or null
     uint32_t* error;              // set non-zero if a bounded spin gave up
@@ -396,6 +398,15 @@ struct SweepArgs {
 #endif
 #ifndef RSX_RANK_GROUP
 #define RSX_RANK_GROUP 4
+#endif
+#ifndef RSX_MINW_BIG
+#define RSX_MINW_BIG 4  // waves/SIMD asked of the compiler for 64-byte-per-thread tiles (u32 x 16)
+#endif
+#ifndef RSX_WIDE_CNT
+#define RSX_WIDE_CNT 1
+#endif
+#ifndef RSX_LB_WIDE
+#define RSX_LB_WIDE 1
 #endif
 #ifndef RSX_DPP_SCAN
 #define RSX_DPP_SCAN 2  // 0 off, 1 on, 2 = where measured faster (elements of <= 4 bytes)
@@ -491,7 +502,7 @@ template <int ES, int KPT, int WG, typename S, int XF, bool NEXT>
 // (measured: 0.82 -> 0.68 ms per 256M-key pass at 2 workgroups/CU without spills).
 // SGPR budget: the hardware admits waves by SGPRs too (800 per SIMD in blocks of 16, +16 per wave):
 // above 80 SGPRs a kernel cannot have 8 waves per SIMD however few VGPRs it uses.
-__global__ __launch_bounds__(WG, (WG == 1024 ? 8 : KPT * (ES < 4 ? 4 : ES) >= 64 ? 4 : RSX_MINW))
+__global__ __launch_bounds__(WG, (WG == 1024 ? 8 : KPT * (ES < 4 ? 4 : ES) >= 64 ? RSX_MINW_BIG : RSX_MINW))
 __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const SweepArgs a) {
     constexpr int NWAVE = WG / WAVE;
     constexpr int TILE = WG * KPT;
@@ -509,7 +520,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
     E* s_elems = reinterpret_cast<E*>(smem);                                           // [TILE]
     // per-wave digit counters: 32-bit where LDS allows (narrow elements run 2 workgroups/CU), else
     // two 16-bit counters per word (saves 4 KiB, costs ~6 VALU per element for shifts and masks)
-    constexpr bool WIDE_CNT = ES <= 4 && KPT >= 16 && WG <= 512;  // where the workgroup runs 2 per CU anyway
+    constexpr bool WIDE_CNT = RSX_WIDE_CNT && ES <= 4 && KPT >= 16 && WG <= 512;  // where the workgroup runs 2 per CU anyway
     using Cnt = typename std::conditional<WIDE_CNT, uint32_t, uint16_t>::type;
     uint32_t* s_whist2 = reinterpret_cast<uint32_t*>(smem + TILE_BYTES);               // the counters as LDS words
     Cnt* s_whist = reinterpret_cast<Cnt*>(s_whist2);                                   // [NWAVE][256]
@@ -684,48 +695,71 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
 #pragma unroll
             for (int j = 0; j < KPT; ++j) key_map<ES, false>(e[j], a.xf);
         }
-        // ---- match + rank within the wave (stable), fused per element.  Match: the lanes sharing
-        // my digit (m).  Rank: every lane reads its digit's running 16-bit count, then the first lane
-        // of each digit group adds the group size with an LDS atomic -- so nothing waits on the
-        // read and the 2*KPT LDS ops pipeline (LDS serves one wave in order); the read results are
-        // consumed a group of RG elements later.  Kept per element: its 16-bit tile rank, two per
-        // VGPR; the digit is re-derived from the element where needed (2 VALU) instead of kept.
+        // ---- rank within the wave (stable): for every element, the number of elements of this wave
+        // with the same digit that come before it in (round, lane) order, plus the wave's running
+        // count of that digit.  Two ways, chosen per tile and wave:
+        //  * ballots: wave64 "match any" (the lanes sharing my digit, m) in 32 hand-scheduled VALU;
+        //    every lane reads its digit's running count, the first lane of each group adds the group
+        //    size with an LDS atomic (the read never feeds the write, so the LDS ops pipeline).
+        //    Cost independent of the digit distribution.
+        //  * LDS atomics: every lane adds 1 to its digit's counter and takes the returned old value as
+        //    its rank.  One LDS instruction instead of ~40 VALU -- but lanes that share an address are
+        //    serialised, and the ranks are stable only if the LDS applies them in ascending lane
+        //    order.  gfx950 does (not an ISA promise): rsx_lds_order_kernel tests exactly that when a
+        //    context first touches the device, and a.rank_atomic is set only if it passed.
+        // Round 0 always goes by ballots; if it shows a digit shared by >= a.hot_lanes lanes (skewed
+        // digits: a constant high byte, few distinct keys) the whole tile does, else the other rounds
+        // use the atomics.  Kept per element: its 16-bit tile rank, two per VGPR; the digit is
+        // re-derived from the element where needed (2 VALU) instead of kept.
         uint32_t pk[(KPT + 1) / 2];
-        auto match_rank = [&](auto is_full) {  // body duplicated per case: the common one stays branch-free
+        auto rank_keys = [&](auto is_full, auto by_atomic, auto j_begin) -> bool {  // bodies duplicated per case
             constexpr bool FULL = decltype(is_full)::value;
-            constexpr int RG = KPT < RSX_RANK_GROUP ? KPT : RSX_RANK_GROUP;
+            constexpr bool ATOM = decltype(by_atomic)::value;
+            constexpr int JB = decltype(j_begin)::value;
+            constexpr int JE = JB == 0 ? 1 : KPT;
+            constexpr int RG = (JE - JB) < RSX_RANK_GROUP ? (JE - JB) : RSX_RANK_GROUP;
+            bool crowded = false;
 #pragma unroll
-            for (int j0 = 0; j0 < KPT; j0 += RG) {
+            for (int j0 = JB; j0 < JE; j0 += RG) {
                 uint32_t below[RG], word[RG], sh[RG];
 #pragma unroll
                 for (int r = 0; r < RG; ++r) {
                     const int j = j0 + r;
+                    if (j >= JE) continue;
                     uint32_t d = elem_digit<ES, false>(e[j], a.spec);
-                    uint64_t m;
-                    if constexpr (FULL) {
-                        m = match_digit_sched(d);
-                    } else {
+                    if constexpr (!FULL) {
                         if (seg + j * WAVE >= valid) d = 255u;
-                        m = match_digit(d);
                     }
-                    below[r] = mbcnt64(m);
-                    if constexpr (WIDE_CNT) {
-                        sh[r] = 0;
-                        word[r] = my_hist2[d];
-                        if (below[r] == 0) atomicAdd(&my_hist2[d], (uint32_t)__popcll(m));
+                    sh[r] = WIDE_CNT ? 0u : (d & 1u) * 16u;  // else two 16-bit counters per LDS word
+                    uint32_t* cnt = &my_hist2[WIDE_CNT ? d : (d >> 1)];
+                    if constexpr (ATOM) {
+                        below[r] = 0;
+                        word[r] = atomicAdd(cnt, 1u << sh[r]);
                     } else {
-                        sh[r] = (d & 1u) * 16u;  // two 16-bit counters per LDS word
-                        word[r] = my_hist2[d >> 1];
-                        if (below[r] == 0) atomicAdd(&my_hist2[d >> 1], (uint32_t)__popcll(m) << sh[r]);
+                        uint64_t m;
+                        if constexpr (FULL) m = match_digit_sched(d);
+                        else m = match_digit(d);
+                        below[r] = mbcnt64(m);
+                        const uint32_t group = (uint32_t)__popcll(m);
+                        word[r] = *cnt;
+                        if (below[r] == 0) atomicAdd(cnt, group << sh[r]);
+                        if constexpr (JB == 0) crowded = __ballot(group >= a.hot_lanes) != 0;
                     }
                 }
 #pragma unroll
                 for (int r = 0; r < RG; ++r) {
                     const int j = j0 + r;
+                    if (j >= JE) continue;
                     const uint32_t rank = (WIDE_CNT ? word[r] : ((word[r] >> sh[r]) & 0xFFFFu)) + below[r];
                     pk[j / 2] = (j & 1) ? (pk[j / 2] | (rank << 16)) : rank;
                 }
             }
+            return crowded;
+        };
+        auto match_rank = [&](auto is_full) {
+            const bool crowded = rank_keys(is_full, std::false_type{}, std::integral_constant<int, 0>{});
+            if (a.rank_atomic && !crowded) rank_keys(is_full, std::true_type{}, std::integral_constant<int, 1>{});
+            else rank_keys(is_full, std::false_type{}, std::integral_constant<int, 1>{});
         };
         if (full) match_rank(std::true_type{});
         else match_rank(std::false_type{});
@@ -795,25 +829,47 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         if (tid < RADIX) {
             uint64_t excl = 0;
             if (kt > 0) {
-                // one predecessor per hop: examining several per round trip was measured slower
-                // (the extra status reads cost more than the saved latency)
+                // LBW predecessors per round trip: the loads are independent, so one round trip (~500
+                // cycles from the chain's L2) can cover several tiles of the walk back
+                constexpr uint32_t LBW = RSX_LB_WIDE;
                 uint64_t row = stat_row - RADIX;  // predecessor in the chain
+                uint32_t left = kt;               // predecessors not yet summed (tiles kt-1 .. 0 of the chain)
                 uint32_t spins = 0, hops = 0;
-                while (true) {
+                bool done = false;
+                while (!done) {
                     ++hops;
-                    const S s = __hip_atomic_load(&status[row + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const uint32_t f = (uint32_t)(s >> Status<S>::SHIFT);
-                    if (f == 0) {
+                    S s[LBW];
+#pragma unroll
+                    for (uint32_t i = 0; i < LBW; ++i)
+                        s[i] = (i == 0 || i < left)
+                                   ? __hip_atomic_load(&status[row - (uint64_t)i * RADIX + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                   : (S)0;
+                    uint32_t used = 0;
+                    bool open = true;  // still summing this batch
+#pragma unroll
+                    for (uint32_t i = 0; i < LBW; ++i) {
+                        const uint32_t f = (uint32_t)(s[i] >> Status<S>::SHIFT);
+                        if (open && f != 0) {
+                            excl += (uint64_t)(s[i] & Status<S>::MASK);
+                            ++used;
+                            if (f == 2) {
+                                done = true;
+                                open = false;
+                            }
+                        } else {
+                            open = false;
+                        }
+                    }
+                    if (done) break;
+                    row -= (uint64_t)used * RADIX;
+                    left -= used;
+                    if (used == 0) {
                         if (++spins > (1u << 22)) {  // bounded: never hang the device
                             atomicExch(a.error, 1u);
                             break;
                         }
                         __builtin_amdgcn_s_sleep(1);
-                        continue;
                     }
-                    excl += (uint64_t)(s & Status<S>::MASK);
-                    if (f == 2) break;
-                    row -= RADIX;
                 }
                 if ((a.dbg & 0x100u) && tid == 0) {  // diagnostics: hop / stall statistics of digit 0
                     atomicAdd(&a.dbg_cnt[0], 1ull);
@@ -879,7 +935,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
     }
 #ifdef RSX_STAMPS
     if ((threadIdx.x & 63) == 0)
-        for (int k = 0; k < 7; ++k) atomicAdd(&a.dbg_cnt[(threadIdx.x >> 6) * 8 + k], stamp_acc[k]);
+        for (int k = 0; k < 8; ++k) atomicAdd(&a.dbg_cnt[(threadIdx.x >> 6) * 8 + k], stamp_acc[k]);
 #endif
 
     if (NEXT) {  // hand this workgroup's share of the next count matrix over
@@ -917,6 +973,45 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 }
 __device__ __forceinline__ uint64_t rand64(uint64_t seed, uint64_t index) {
     return splitmix64(seed + index * 0x9E3779B97F4A7C15ull);
+}
+
+// ------------------------------------------------------------- LDS atomic order --
+// Self-test behind a.rank_atomic: when several lanes of ONE ds_add_rtn instruction hit the same
+// address, the sweep needs them applied in ascending lane order (then the returned values are
+// stable ranks).  The ISA documents no order, so it is established on the device at hand: 64
+// address patterns (1..256 distinct addresses; hashed, lane-cyclic, blocked and same-bank layouts;
+// both the 32-bit and the packed 16-bit counter forms), every lane checks its two returned values
+// against the ballot-derived rank.  Any mismatch sets *fail and the sweep keeps to ballots.
+__global__ __launch_bounds__(512) void rsx_lds_order_kernel(uint32_t* __restrict__ fail) {
+    __shared__ uint32_t cnt[8][RADIX];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    static constexpr uint32_t BINS[8] = {1, 2, 3, 5, 16, 64, 256, 256};
+    uint32_t bad = 0;
+    for (uint32_t p = 0; p < 64; ++p) {
+        for (uint32_t i = lane; i < RADIX; i += WAVE) cnt[wave][i] = 0;  // LDS serves one wave in order
+        const uint32_t bins = BINS[p & 7];
+        const uint32_t h = (uint32_t)(splitmix64(((uint64_t)blockIdx.x << 32) ^ (p << 16) ^ (wave << 8) ^ lane) >> 32);
+        uint32_t d;
+        switch ((p >> 3) & 3) {
+            case 0: d = h % bins; break;                        // hashed
+            case 1: d = lane % bins; break;                     // cyclic: neighbours differ
+            case 2: d = (lane * bins) / WAVE; break;            // blocked: neighbours share
+            default: d = ((h % bins) * 32u) % RADIX; break;     // distinct addresses in one bank
+        }
+        const uint64_t m = match_digit<8>(d);
+        const uint32_t below = mbcnt64(m), group = (uint32_t)__popcll(m);
+        uint32_t r1, r2;
+        if (p & 32) {  // packed: two 16-bit counters per word
+            const uint32_t sh = (d & 1u) * 16u;
+            r1 = (atomicAdd(&cnt[wave][d >> 1], 1u << sh) >> sh) & 0xFFFFu;
+            r2 = (atomicAdd(&cnt[wave][d >> 1], 1u << sh) >> sh) & 0xFFFFu;
+        } else {
+            r1 = atomicAdd(&cnt[wave][d], 1u);
+            r2 = atomicAdd(&cnt[wave][d], 1u);
+        }
+        if (r1 != below || r2 != group + below) bad = 1;
+    }
+    if (__ballot(bad != 0) != 0 && lane == 0) atomicOr(fail, 1u);
 }
 
 // key (as up to 128 bits lo/hi) for generator `gen`

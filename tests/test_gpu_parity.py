@@ -255,10 +255,15 @@ def test_verify_detects_errors(rs, torch, ctx):
     assert out[0].item() == 0 and out[2].item() == n - 1
 
 
-def test_dynamic_ticket_mode_matches(orc):
-    """The fallback tile distribution (agent-scope tickets, RSX_DEBUG bit 0x2000 forces it) must give
-    the same bytes as the static roll-call mode.  Runs in a child process: the switch is read once
-    per context from the environment."""
+@pytest.mark.parametrize("switch,what", [("0x2000", "dynamic tile tickets instead of the static roll-call assignment"),
+                                         ("0x10000", "ranks by ballots only"),
+                                         ("0x20000", "ranks by returned LDS atomics whatever the skew"),
+                                         ("0x8000", "agent-scope status stores even on verified single-XCD chains"),
+                                         ("0x4000", "no XCD-major workgroup numbering")])
+def test_alternative_kernel_paths_match(orc, switch, what):
+    """Every fallback / alternative path of the sweep kernel (selected by an RSX_DEBUG bit) must give
+    the same bytes as the default path.  Runs in a child process: the switches are read once per
+    context from the environment."""
     import subprocess
     import sys
     code = r'''
@@ -268,19 +273,33 @@ import numpy as np, torch, util
 import radix_sort_amd as rs
 from oracle import oracle
 ctx = rs.default_context(0)
-for t, n in (("u32", 3000001), ("(u64,u64)", 700001), ("f32", 1500000), ("u8", 5000000)):
+for t, n, dist in (("u32", 3000001, "uniform"), ("(u64,u64)", 700001, "zipf"), ("f32", 1500000, "uniform"),
+                   ("u8", 5000000, "uniform"), ("(u8,[u8;7])", 2000003, "two"), ("(u32,u32)", 1000001, "step16"),
+                   ("(i16,u16)", 1234567, "equal"), ("u64", 2000001, "lowbyte"), ("(u32,[u8;8])", 500009, "zipf")):
     d = rs.RadixDigits(*util.TYPES[t])
-    raw = util.make_input(t, n, "uniform" if t != "(u64,u64)" else "zipf", seed=31)
+    raw = util.make_input(t, n, dist, seed=31)
     x = torch.from_numpy(raw.copy()).cuda()
     rs.radix_sort(x, digits=d); ctx.check()
     exp = oracle.sort_parallel(raw, oracle.Layout(*util.TYPES[t]), 8)
-    assert np.array_equal(x.cpu().numpy(), exp), t
-print("DYNAMIC OK")
+    assert np.array_equal(x.cpu().numpy(), exp), (t, dist)
+print("PATH OK")
 '''
-    env = dict(os.environ, RSX_DEBUG="0x2000")
+    env = dict(os.environ, RSX_DEBUG=switch)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "DYNAMIC OK" in out.stdout, out.stdout + out.stderr
+    assert out.returncode == 0 and "PATH OK" in out.stdout, what + "\n" + out.stdout + out.stderr
+
+
+def test_lds_atomic_order_selftest_passes_on_gfx950():
+    """The sweep ranks by returned LDS atomics only if rsx_lds_order_kernel passed on this device;
+    on gfx950 it is expected to (otherwise the bench numbers are those of the ballot path)."""
+    import subprocess
+    import sys
+    code = "import torch, radix_sort_amd as rs; x = torch.arange(100000, 0, -1, dtype=torch.int32, device='cuda'); rs.radix_sort(x); torch.cuda.synchronize()"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, RSX_DEBUG="0x200"),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "self-test passed" in out.stderr, out.stdout + out.stderr
 
 
 def test_many_sorts_one_context_and_graph_capture(rs, torch, ctx):
