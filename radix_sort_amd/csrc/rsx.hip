@@ -43,6 +43,8 @@ struct rsx_ctx {
     size_t host_bytes = 0;
     int num_cu = 256;
     uint32_t stagger = 1;  // RSX_STAGGER env (tuning)
+    uint32_t pass_index = 0;   // of the sweep being launched within its sort (selects the status half)
+    bool pass_last = true;     // no pass follows: nothing to clean
     bool rank_atomic = false;  // LDS atomic ordering self-test passed (set when the workspace is first made)
     uint32_t hot_lanes = 8;    // RSX_HOT env (tuning)
     uint32_t dbg = 0;  // RSX_DEBUG env: timing-only ablation switches for the sweep kernel
@@ -215,7 +217,7 @@ int ensure_workspace(rsx_ctx* ctx, size_t n, const rsx_layout* L) {
         if (ctx->status) RSX_HIP(hipFree(ctx->status));
         ctx->status = nullptr;
         ctx->status_bytes = 0;
-        hipError_t e = hipMalloc(&ctx->status, need);
+        hipError_t e = hipMalloc(&ctx->status, 2 * need);  // two arrays: this pass's and the next pass's
         if (e != hipSuccess) return fail(ctx, RSX_ERR_NOMEM, "workspace hipMalloc", e);
         ctx->status_bytes = need;
     }
@@ -284,13 +286,18 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
     constexpr int SWEEP_WG = wg_for(ES);
     constexpr int TILE = SWEEP_WG * KPT;
     const uint64_t rows = status_rows(g, ES);
-    RSX_HIP(hipMemsetAsync(ctx->status, 0, (size_t)rows * RADIX * sizeof(S), st));
+    // Status words alternate between the two halves of the workspace.  Only the first pass of a
+    // sort zeroes its half with a memset; every pass zeroes, tile by tile, the half of the next.
+    char* const half[2] = {static_cast<char*>(ctx->status), static_cast<char*>(ctx->status) + ctx->status_bytes};
+    const uint32_t which = ctx->pass_index & 1u;
+    if (ctx->pass_index == 0) RSX_HIP(hipMemsetAsync(half[0], 0, (size_t)rows * RADIX * sizeof(S), st));
     SweepArgs a;
+    a.status_clean = ctx->pass_last ? nullptr : half[which ^ 1u];
     a.src = src;
     a.dst = dst;
     a.g = g;
     a.region_base = base_of(ctx);
-    a.status = ctx->status;
+    a.status = half[which];
     a.tickets = tickets_of(ctx);
     a.jnext = jnext;
     a.error = error_of(ctx);
@@ -606,6 +613,8 @@ int rsx_sort_device(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const rsx
         rc = launch_prefix(ctx, geom, J_of(ctx, d & 1), jnext, nullptr, st);  // mod.rs:110-120
         if (rc) return rc;
         const int xf = (d == 0 ? 1 : 0) | (d + 1 == D ? 2 : 0);  // key map on at the first, off at the last pass
+        ctx->pass_index = d;
+        ctx->pass_last = d + 1 == D;
         rc = sweep_dispatch(ctx, src, dst, geom, L, d, jnext, xf, st);  // mod.rs:121-168
         if (rc) return rc;
     }
@@ -698,6 +707,8 @@ int rsx_partition_device(rsx_ctx* ctx, const void* d_src, void* d_dst, size_t n,
     if (rc) return rc;
     rc = launch_prefix(ctx, geom, J_of(ctx, 0), nullptr, d_hist, st);
     if (rc) return rc;
+    ctx->pass_index = 0;
+    ctx->pass_last = true;
     return sweep_dispatch(ctx, d_src, d_dst, geom, L, digit, nullptr, 3, st);  // a lone pass maps and unmaps
 } catch (...) {
     return RSX_ERR_HIP;

@@ -353,6 +353,7 @@ struct SweepArgs {
     uint32_t* tickets;            // [MAX_REGIONS] per-region tile counters, zeroed; [MAX_REGIONS], [MAX_REGIONS+1]:
                                   // arrival count and mode word of the start-up roll call, zeroed
     uint16_t wg_first[MAX_REGIONS + 1];  // static mode: region r is served by workgroups [wg_first[r], wg_first[r+1])
+    void* status_clean;           // the next pass's status words: every tile zeroes its row there (null on a last pass)
     uint32_t rank_atomic;         // 1: ranks may come from returned LDS atomics (ordering self-test passed)
     uint32_t hot_lanes;           // a digit shared by this many lanes of round 0 sends the tile down the ballot path
     uint32_t local_mask;          // static mode: regions whose workgroups all sit in one residue class of blockIdx % 8
@@ -404,6 +405,12 @@ struct SweepArgs {
 #endif
 #ifndef RSX_WIDE_CNT
 #define RSX_WIDE_CNT 1
+#endif
+#ifndef RSX_WO_GROUP
+#define RSX_WO_GROUP 4  // write-out: elements in flight between scheduling barriers
+#endif
+#ifndef RSX_EARLY_HOP
+#define RSX_EARLY_HOP 2  // 0 off, 1 on, 2 = where measured faster (elements of <= 4 bytes)
 #endif
 #ifndef RSX_LB_WIDE
 #define RSX_LB_WIDE 1
@@ -509,6 +516,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
     constexpr int TILE_LOG = __builtin_ctz(TILE);
     // next-tile prefetch keeps the element registers live through the write-out: only where that fits
     // the VGPR budget without spilling (u32 x 16 keys does not at 80 VGPRs, and is VALU-bound anyway)
+    constexpr bool EARLY_HOP = RSX_EARLY_HOP == 1 || (RSX_EARLY_HOP == 2 && ES <= 4);
     constexpr bool PREFETCH = RSX_PREFETCH_ALL != 0 && (RSX_PREFETCH_ALL != 3 || ES >= 12);
     static_assert((TILE & (TILE - 1)) == 0, "tile size must be a power of two (regions are whole tiles)");
     static_assert(WG >= RADIX, "need one thread per digit");
@@ -779,6 +787,14 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
             const S flag = (kt == 0) ? (S)2 : (S)1;  // first tile of a chain: aggregate == inclusive
             publish(&status[stat_row + tid], (flag << Status<S>::SHIFT) | (S)real);
         }
+        // the status words of the NEXT pass live in a second array; each tile zeroes its row there,
+        // which spares a memset launch per pass
+        if (a.status_clean != nullptr && tid < RADIX) static_cast<S*>(a.status_clean)[stat_row + tid] = 0;
+        // first hop of the look-back, requested now and looked at after the LDS reorder: an
+        // aggregate or inclusive word stays true however old it is; an empty one is read again
+        S early = 0;
+        if (EARLY_HOP && tid < RADIX && kt > 0)
+            early = __hip_atomic_load(&status[stat_row - RADIX + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // exclusive scan of tcount over the 256 digits -> start of each digit's run in the tile
         uint32_t incl = tcount;
         if (tid < RADIX) {
@@ -839,11 +855,15 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                 while (!done) {
                     ++hops;
                     S s[LBW];
+                    if (EARLY_HOP && LBW == 1 && hops == 1 && (early >> Status<S>::SHIFT) != 0) {
+                        s[0] = early;
+                    } else {
 #pragma unroll
-                    for (uint32_t i = 0; i < LBW; ++i)
-                        s[i] = (i == 0 || i < left)
-                                   ? __hip_atomic_load(&status[row - (uint64_t)i * RADIX + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                   : (S)0;
+                        for (uint32_t i = 0; i < LBW; ++i)
+                            s[i] = (i == 0 || i < left)
+                                       ? __hip_atomic_load(&status[row - (uint64_t)i * RADIX + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                       : (S)0;
+                    }
                     uint32_t used = 0;
                     bool open = true;  // still summing this batch
 #pragma unroll
@@ -908,7 +928,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                     if (NEXT && !(a.dbg & 16u))
                         count_next(s_jn, ((uint32_t)(idx >> a.g.region_shift) << 8) | elem_digit<ES, false>(x, a.next));
                     // bound the look-ahead: x + 64-bit base per element in flight is 3 VGPRs each
-                    if (i % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+                    if (i % RSX_WO_GROUP == RSX_WO_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
 #pragma unroll
