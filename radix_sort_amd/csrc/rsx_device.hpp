@@ -912,24 +912,48 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         // ---- count the NEXT pass's digit per destination region on the way out
         if (!(a.dbg & 2u)) {
             E* __restrict__ dst = static_cast<E*>(a.dst);
+            // bin of the next pass's count matrix: (destination region, next digit)
+            auto next_bin = [&](uint64_t idx, const E& x) -> uint32_t {
+                uint32_t r;
+                if constexpr (sizeof(S) == 4)  // 32-bit status words <=> region_shift <= 30: one funnel shift
+                    r = __builtin_amdgcn_alignbit((uint32_t)(idx >> 32), (uint32_t)idx, a.g.region_shift);
+                else
+                    r = (uint32_t)(idx >> a.g.region_shift);
+                return (r << 8) | elem_digit<ES, false>(x, a.next);
+            };
             if (full) {
+                auto write_full = [&](auto crowd) {  // duplicated: plain LDS atomics / skew-proof counting
+                    constexpr bool CROWD = decltype(crowd)::value;
 #pragma unroll
-                for (int i = 0; i < KPT; ++i) {
-                    const uint32_t p = i * WG + tid;
-                    const E x = s_elems[p];
-                    const uint64_t idx = s_base[elem_digit<ES, false>(x, a.spec)] + p;
-                    if constexpr ((XF & 2) != 0) {  // last pass: back to the caller's representation
-                        E y = x;
-                        key_map<ES, true>(y, a.xf);
-                        dst[idx] = y;
-                    } else {
-                        dst[idx] = x;
+                    for (int i = 0; i < KPT; ++i) {
+                        const uint32_t p = i * WG + tid;
+                        const E x = s_elems[p];
+                        const uint64_t idx = s_base[elem_digit<ES, false>(x, a.spec)] + p;
+                        if constexpr ((XF & 2) != 0) {  // last pass: back to the caller's representation
+                            E y = x;
+                            key_map<ES, true>(y, a.xf);
+                            dst[idx] = y;
+                        } else {
+                            dst[idx] = x;
+                        }
+                        if (NEXT && !(a.dbg & 16u)) {
+                            if constexpr (CROWD) count_next(s_jn, next_bin(idx, x));
+                            else atomicAdd(&s_jn[next_bin(idx, x)], 1u);
+                        }
+                        // bound the look-ahead: x + 64-bit base per element in flight is 3 VGPRs each
+                        if (i % RSX_WO_GROUP == RSX_WO_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (NEXT && !(a.dbg & 16u))
-                        count_next(s_jn, ((uint32_t)(idx >> a.g.region_shift) << 8) | elem_digit<ES, false>(x, a.next));
-                    // bound the look-ahead: x + 64-bit base per element in flight is 3 VGPRs each
-                    if (i % RSX_WO_GROUP == RSX_WO_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+                };
+                // Same-address LDS atomics serialise.  One probe per wave and tile: if a quarter of the
+                // wave's first 64 elements share their next digit, count the careful way (per-element
+                // check, wave match on crowded bins); else one plain atomic per element.
+                bool crowded_next = false;
+                if (NEXT) {
+                    const uint32_t nd = elem_digit<ES, false>(s_elems[tid], a.next);
+                    crowded_next = __popcll(__ballot(nd == (uint32_t)__builtin_amdgcn_readfirstlane((int)nd))) >= 16;
                 }
+                if (crowded_next) write_full(std::true_type{});
+                else write_full(std::false_type{});
             } else {
 #pragma unroll
                 for (int i = 0; i < KPT; ++i) {
@@ -945,7 +969,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                             dst[idx] = x;
                         }
                         if (NEXT)
-                            count_next(s_jn, ((uint32_t)(idx >> a.g.region_shift) << 8) | elem_digit<ES, false>(x, a.next));
+                            count_next(s_jn, next_bin(idx, x));
                     }
                 }
             }
