@@ -42,6 +42,8 @@ WORKLOADS = {
     "f32-256m": ("f32", 28, "uniform", 0.0, "256M f32 keys (uniform bit patterns: NaNs, infinities, both signs)"),
     "i32-256m": ("i32", 28, "uniform", 0.0, "256M i32 uniform keys"),
     "f64-128m": ("f64", 27, "uniform", 0.0, "128M f64 keys (uniform bit patterns)"),
+    "sorted-256m-u32": ("u32", 28, "sorted", 0.0, "256M u32 keys already in order (key = index)"),
+    "reversed-256m-u32": ("u32", 28, "reversed", 0.0, "256M u32 keys in reverse order"),
     "pairs-128m-u64u64": ("(u64,u64)", 27, "uniform", 0.0, "128M (u64,u64) pairs (reference bench type, main.rs:123)"),
 }
 EXTRA_DEFAULT = ["target-1b-u32", "c3-1b-u64", "zipf-256m-u32", "step16-256m-u32"]
@@ -55,7 +57,8 @@ def digits_for(rs, t):
 
 
 def gen_id(rs, name):
-    return {"uniform": rs.GEN_UNIFORM, "zipf": rs.GEN_ZIPF, "step": rs.GEN_STEP}[name]
+    return {"uniform": rs.GEN_UNIFORM, "zipf": rs.GEN_ZIPF, "step": rs.GEN_STEP, "sorted": rs.GEN_SORTED,
+            "reversed": rs.GEN_REVERSED}[name]
 
 
 def run_single(rs, torch, ctx, wl, steps, warmup, seed0=0x5EED0000, profile=True):

@@ -46,7 +46,7 @@ struct rsx_ctx {
     uint32_t pass_index = 0;   // of the sweep being launched within its sort (selects the status half)
     bool pass_last = true;     // no pass follows: nothing to clean
     bool rank_atomic = false;  // LDS atomic ordering self-test passed (set when the workspace is first made)
-    uint32_t hot_lanes = 8;    // RSX_HOT env (tuning)
+    uint32_t hot_lanes = 16;   // RSX_HOT env (tuning)
     uint32_t dbg = 0;  // RSX_DEBUG env: timing-only ablation switches for the sweep kernel
     // per-launch HIP-event timing (rsx_ctx_profile)
     bool prof = false;

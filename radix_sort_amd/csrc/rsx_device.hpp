@@ -412,6 +412,9 @@ struct SweepArgs {
 #ifndef RSX_EARLY_HOP
 #define RSX_EARLY_HOP 2  // 0 off, 1 on, 2 = where measured faster (elements of <= 4 bytes)
 #endif
+#ifndef RSX_MINW_1024
+#define RSX_MINW_1024 8
+#endif
 #ifndef RSX_LB_WIDE
 #define RSX_LB_WIDE 1
 #endif
@@ -474,11 +477,12 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
 }
 
 __device__ __forceinline__ void count_next(uint32_t* s_jn, uint32_t bin) {
-    const uint32_t b0 = __builtin_amdgcn_readfirstlane(bin);
+    // careful form (crowded bins): the lanes that share the first lane's bin add their number once,
+    // the others add 1 each -- same-address LDS atomics of one instruction are serialised
+    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)bin);
     const uint64_t same = __ballot(bin == b0);
-    if (__popcll(same) >= 16) {  // wave-uniform
-        const uint64_t m = match_digit<12>(bin) & __builtin_amdgcn_read_exec();
-        if (mbcnt64(m) == 0) atomicAdd(&s_jn[bin], (uint32_t)__popcll(m));
+    if (bin == b0) {
+        if (mbcnt64(same) == 0) atomicAdd(&s_jn[b0], (uint32_t)__popcll(same));
     } else {
         atomicAdd(&s_jn[bin], 1u);
     }
@@ -509,7 +513,7 @@ template <int ES, int KPT, int WG, typename S, int XF, bool NEXT>
 // (measured: 0.82 -> 0.68 ms per 256M-key pass at 2 workgroups/CU without spills).
 // SGPR budget: the hardware admits waves by SGPRs too (800 per SIMD in blocks of 16, +16 per wave):
 // above 80 SGPRs a kernel cannot have 8 waves per SIMD however few VGPRs it uses.
-__global__ __launch_bounds__(WG, (WG == 1024 ? 8 : KPT * (ES < 4 ? 4 : ES) >= 64 ? RSX_MINW_BIG : RSX_MINW))
+__global__ __launch_bounds__(WG, (WG == 1024 ? RSX_MINW_1024 : KPT * (ES < 4 ? 4 : ES) >= 64 ? RSX_MINW_BIG : RSX_MINW))
 __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const SweepArgs a) {
     constexpr int NWAVE = WG / WAVE;
     constexpr int TILE = WG * KPT;
@@ -720,7 +724,9 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         // use the atomics.  Kept per element: its 16-bit tile rank, two per VGPR; the digit is
         // re-derived from the element where needed (2 VALU) instead of kept.
         uint32_t pk[(KPT + 1) / 2];
-        auto rank_keys = [&](auto is_full, auto by_atomic, auto j_begin) -> bool {  // bodies duplicated per case
+        uint64_t crowd = 0;   // round 0: lanes whose digit is shared by >= a.hot_lanes lanes
+        uint32_t digit0 = 0;  // round 0: this lane's digit
+        auto rank_keys = [&](auto is_full, auto by_atomic, auto j_begin) __attribute__((always_inline)) -> bool {  // bodies duplicated per case
             constexpr bool FULL = decltype(is_full)::value;
             constexpr bool ATOM = decltype(by_atomic)::value;
             constexpr int JB = decltype(j_begin)::value;
@@ -745,13 +751,26 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                         word[r] = atomicAdd(cnt, 1u << sh[r]);
                     } else {
                         uint64_t m;
-                        if constexpr (FULL) m = match_digit_sched(d);
-                        else m = match_digit(d);
+                        if constexpr (FULL && JB != 0) {
+                            // crowded tiles (the only ones that come here past round 0) often have rounds
+                            // where the whole wave holds ONE digit -- a constant byte, sorted input: no match needed
+                            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+                            if (__ballot(d != d0) == 0) m = ~0ull;
+                            else m = match_digit_sched(d);
+                        } else if constexpr (FULL) {
+                            m = match_digit_sched(d);
+                        } else {
+                            m = match_digit(d);
+                        }
                         below[r] = mbcnt64(m);
                         const uint32_t group = (uint32_t)__popcll(m);
                         word[r] = *cnt;
                         if (below[r] == 0) atomicAdd(cnt, group << sh[r]);
-                        if constexpr (JB == 0) crowded = __ballot(group >= a.hot_lanes) != 0;
+                        if constexpr (JB == 0) {
+                            crowd = __ballot(group >= a.hot_lanes);
+                            digit0 = d;
+                            crowded = crowd != 0;
+                        }
                     }
                 }
 #pragma unroll
@@ -764,10 +783,62 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
             }
             return crowded;
         };
-        auto match_rank = [&](auto is_full) {
+        // One dominant digit per round (a constant byte, sorted input, the head of a Zipf law): the
+        // lanes holding it are ranked from a single ballot (counter read + one add by the first of
+        // them); the other lanes use the atomics under their exec mask.  The round's dominant digit
+        // is the tile's (largest group of round 0) when some lane holds it, else the first lane's.
+        auto rank_hot = [&](auto is_full, uint32_t hotd) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(is_full)::value;
+            constexpr int RG = (KPT - 1) < RSX_RANK_GROUP ? (KPT - 1) : RSX_RANK_GROUP;
+#pragma unroll
+            for (int j0 = 1; j0 < KPT; j0 += RG) {
+                uint32_t word[RG], sh[RG], below[RG];
+#pragma unroll
+                for (int r = 0; r < RG; ++r) {
+                    const int j = j0 + r;
+                    if (j >= KPT) continue;
+                    uint32_t d = elem_digit<ES, false>(e[j], a.spec);
+                    if constexpr (!FULL) {
+                        if (seg + j * WAVE >= valid) d = 255u;
+                    }
+                    uint32_t hd = hotd;
+                    uint64_t h = __ballot(d == hd);
+                    if (h == 0) {  // wave-uniform
+                        hd = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+                        h = __ballot(d == hd);
+                    }
+                    sh[r] = WIDE_CNT ? 0u : (d & 1u) * 16u;
+                    uint32_t* cnt = &my_hist2[WIDE_CNT ? d : (d >> 1)];
+                    if (d == hd) {
+                        below[r] = mbcnt64(h);
+                        word[r] = *cnt;
+                        if (below[r] == 0) atomicAdd(cnt, (uint32_t)__popcll(h) << sh[r]);
+                    } else {
+                        below[r] = 0;
+                        word[r] = atomicAdd(cnt, 1u << sh[r]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < RG; ++r) {
+                    const int j = j0 + r;
+                    if (j >= KPT) continue;
+                    const uint32_t rank = (WIDE_CNT ? word[r] : ((word[r] >> sh[r]) & 0xFFFFu)) + below[r];
+                    pk[j / 2] = (j & 1) ? (pk[j / 2] | (rank << 16)) : rank;
+                }
+            }
+        };
+        auto match_rank = [&](auto is_full) __attribute__((always_inline)) {
             const bool crowded = rank_keys(is_full, std::false_type{}, std::integral_constant<int, 0>{});
-            if (a.rank_atomic && !crowded) rank_keys(is_full, std::true_type{}, std::integral_constant<int, 1>{});
-            else rank_keys(is_full, std::false_type{}, std::integral_constant<int, 1>{});
+            if (a.rank_atomic && !crowded) {
+                rank_keys(is_full, std::true_type{}, std::integral_constant<int, 1>{});
+            } else if (a.rank_atomic) {
+                // is every crowded lane of round 0 on ONE digit?
+                const uint32_t hotd = (uint32_t)__builtin_amdgcn_readlane((int)digit0, (int)__builtin_ctzll(crowd));
+                if ((crowd & ~__ballot(digit0 == hotd)) == 0) rank_hot(is_full, hotd);
+                else rank_keys(is_full, std::false_type{}, std::integral_constant<int, 1>{});
+            } else {
+                rank_keys(is_full, std::false_type{}, std::integral_constant<int, 1>{});
+            }
         };
         if (full) match_rank(std::true_type{});
         else match_rank(std::false_type{});
@@ -922,7 +993,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                 return (r << 8) | elem_digit<ES, false>(x, a.next);
             };
             if (full) {
-                auto write_full = [&](auto crowd) {  // duplicated: plain LDS atomics / skew-proof counting
+                auto write_full = [&](auto crowd) __attribute__((always_inline)) {  // duplicated: plain LDS atomics / skew-proof counting
                     constexpr bool CROWD = decltype(crowd)::value;
 #pragma unroll
                     for (int i = 0; i < KPT; ++i) {
@@ -936,11 +1007,12 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                         } else {
                             dst[idx] = x;
                         }
-                        if (NEXT && !(a.dbg & 16u)) {
+                        if constexpr (NEXT) {
                             if constexpr (CROWD) count_next(s_jn, next_bin(idx, x));
                             else atomicAdd(&s_jn[next_bin(idx, x)], 1u);
                         }
-                        // bound the look-ahead: x + 64-bit base per element in flight is 3 VGPRs each
+                        // (element by element on purpose: issuing a group's LDS reads ahead of its atomics was
+                        // measured no faster on u32 and slower on 8/16-byte elements)
                         if (i % RSX_WO_GROUP == RSX_WO_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
                     }
                 };
