@@ -611,7 +611,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
     }
     // A chain whose workgroups were all verified on ONE XCD shares one L2: its status words can then
     // be plain stores that stay in that L2 (an agent-scope store writes through to memory and the
-    // next agent-scope load of the line misses: 750 vs 510 cycles per hand-off, scratch/pingpong.hip).
+    // next agent-scope load of the line misses: 750 vs 510 cycles per hand-off, tools/microbench/pingpong.hip).
     // The loads stay agent-scope (they bypass the reader's L1 and hit the L2).  Speed only: without
     // the proof every status store is agent-scope.
     const bool local_chain = mode == 3u && ((a.local_mask >> home) & 1u) != 0u && !(a.dbg & 0x8000u);
