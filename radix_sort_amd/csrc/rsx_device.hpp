@@ -415,6 +415,9 @@ struct SweepArgs {
 #ifndef RSX_MINW_1024
 #define RSX_MINW_1024 8
 #endif
+#ifndef RSX_LDS_SWIZZLE
+#define RSX_LDS_SWIZZLE 1
+#endif
 #ifndef RSX_LB_WIDE
 #define RSX_LB_WIDE 1
 #endif
@@ -894,7 +897,11 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
             const uint32_t d = (!full && seg + j * WAVE >= valid) ? 255u : elem_digit<ES, false>(e[j], a.spec);
-            s_elems[my_hist[d] + ((pk[j / 2] >> (16 * (j & 1))) & 0xFFFFu)] = e[j];
+            // bank swizzle (RSX_LDS_SWIZZLE): slot p lives at p ^ ((p >> 5) & 31).  Digit runs that start
+            // a multiple of 32 slots apart -- every pass over already sorted input, key = index -- would
+            // otherwise put all 64 lanes of a wave on one bank
+            const uint32_t pos = my_hist[d] + ((pk[j / 2] >> (16 * (j & 1))) & 0xFFFFu);
+            s_elems[RSX_LDS_SWIZZLE ? (pos ^ ((pos >> 5) & 31u)) : pos] = e[j];
         }
         __syncthreads();  // s_whist is dead from here: s_base takes its place
         RSX_STAMP(4);
@@ -983,6 +990,12 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         // ---- count the NEXT pass's digit per destination region on the way out
         if (!(a.dbg & 2u)) {
             E* __restrict__ dst = static_cast<E*>(a.dst);
+            // physical LDS slot of logical slot i*WG + tid (see the swizzle at the reorder): only the low
+            // five bits change, by (i*WG/32 + tid/32) & 31 -- two values per thread when WG % 512 == 0
+            static_assert(!RSX_LDS_SWIZZLE || WG % 512 == 0, "swizzle constants assume WG % 512 == 0");
+            const uint32_t sw0 = RSX_LDS_SWIZZLE ? (tid ^ ((tid >> 5) & 31u)) : tid;
+            const uint32_t sw1 = RSX_LDS_SWIZZLE ? (tid ^ (((tid >> 5) + (WG >> 5)) & 31u)) : tid;
+            auto slot_of = [&](int i) __attribute__((always_inline)) { return (uint32_t)(i * WG) + ((i & 1) ? sw1 : sw0); };
             // bin of the next pass's count matrix: (destination region, next digit)
             auto next_bin = [&](uint64_t idx, const E& x) -> uint32_t {
                 uint32_t r;
@@ -998,7 +1011,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
 #pragma unroll
                     for (int i = 0; i < KPT; ++i) {
                         const uint32_t p = i * WG + tid;
-                        const E x = s_elems[p];
+                        const E x = s_elems[slot_of(i)];
                         const uint64_t idx = s_base[elem_digit<ES, false>(x, a.spec)] + p;
                         if constexpr ((XF & 2) != 0) {  // last pass: back to the caller's representation
                             E y = x;
@@ -1021,7 +1034,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                 // check, wave match on crowded bins); else one plain atomic per element.
                 bool crowded_next = false;
                 if (NEXT) {
-                    const uint32_t nd = elem_digit<ES, false>(s_elems[tid], a.next);
+                    const uint32_t nd = elem_digit<ES, false>(s_elems[sw0], a.next);
                     crowded_next = __popcll(__ballot(nd == (uint32_t)__builtin_amdgcn_readfirstlane((int)nd))) >= 16;
                 }
                 if (crowded_next) write_full(std::true_type{});
@@ -1031,7 +1044,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                 for (int i = 0; i < KPT; ++i) {
                     const uint32_t p = i * WG + tid;
                     if (p < valid) {
-                        const E x = s_elems[p];
+                        const E x = s_elems[slot_of(i)];
                         const uint64_t idx = s_base[elem_digit<ES, false>(x, a.spec)] + p;
                         if constexpr ((XF & 2) != 0) {
                             E y = x;
