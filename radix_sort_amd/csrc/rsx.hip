@@ -122,20 +122,30 @@ uint32_t elem_align(uint32_t es) {
 }
 bool aligned(const void* p, uint32_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
-// keys per thread by element size: a power of two, LDS tile of 24..32 KiB for ES >= 4
+// Keys per thread by element size.  Tiles need not be powers of two (the last tile of a region is
+// partial anyway); bigger tiles mean longer output runs per digit (fewer partial cache lines, the
+// memory system's real cost here) and fewer look-backs per key, as long as two or three workgroups
+// still fit a CU: u32 28 x 512 = 14336 keys (56 KiB), u64 12 x 512 (48 KiB), 16-byte 5 x 512 (40 KiB).
+// Measured against 16 / 8 / 4: 1B u32 117 -> 136, 1B u64 32 -> 34.9, 128M (u64,u64) 17.3 -> 18 Gkeys/s.
 #ifndef RSX_KPT4
-#define RSX_KPT4 16
+#define RSX_KPT4 28
 #endif
 #ifndef RSX_WG4
 #define RSX_WG4 512
 #endif
 #ifndef RSX_KPT8
-#define RSX_KPT8 8
+#define RSX_KPT8 12
+#endif
+#ifndef RSX_KPT16
+#define RSX_KPT16 5
+#endif
+#ifndef RSX_KPT32
+#define RSX_KPT32 2
 #endif
 #ifndef RSX_WG8
 #define RSX_WG8 512
 #endif
-constexpr int kpt_for(int es) { return es <= 4 ? RSX_KPT4 : es == 8 ? RSX_KPT8 : es <= 16 ? 4 : 2; }
+constexpr int kpt_for(int es) { return es <= 4 ? RSX_KPT4 : es == 8 ? RSX_KPT8 : es <= 16 ? RSX_KPT16 : RSX_KPT32; }
 constexpr int wg_for(int es) { return es <= 4 ? RSX_WG4 : es == 8 ? RSX_WG8 : 512; }
 constexpr uint32_t tile_elems(int es) { return wg_for(es) * kpt_for(es); }
 
@@ -146,21 +156,26 @@ RegionGeom make_geom(uint64_t n, uint32_t es) {
     RegionGeom g;
     g.n = n;
     uint32_t k = log2u(tile_elems((int)es));
+    if ((1ull << k) < tile_elems((int)es)) ++k;  // tiles need not be a power of two; regions are
     static const uint64_t max_regions = [] {  // RSX_REGIONS env: tuning/diagnostics only
         const char* e = std::getenv("RSX_REGIONS");
         const uint64_t v = e ? std::strtoull(e, nullptr, 0) : 0;
         return (v >= 1 && v <= (uint64_t)MAX_REGIONS) ? v : 0;
     }();
-    // narrow elements run 2 workgroups/CU and have LDS to spare for a 32-row count matrix
-    const uint64_t cap = max_regions ? max_regions : 16;  // 32 (possible for narrow elements) measured no faster
+    // the next pass's count matrix costs 1 KiB of LDS per region: 8 where the tile needs the room
+    const uint64_t cap = max_regions ? max_regions : (es == 8 || es > 16) ? 16 : 8;
     while (((n + (1ull << k) - 1) >> k) > cap) ++k;
     g.region_shift = k;
     g.num_regions = (uint32_t)((n + (1ull << k) - 1) >> k);
     if (g.num_regions == 0) g.num_regions = 1;
     return g;
 }
+uint64_t tiles_per_region(const RegionGeom& g, uint32_t es) {
+    const uint64_t t = tile_elems((int)es);
+    return ((1ull << g.region_shift) + t - 1) / t;
+}
 uint64_t status_rows(const RegionGeom& g, uint32_t es) {
-    return (uint64_t)g.num_regions << (g.region_shift - log2u(tile_elems((int)es)));
+    return (uint64_t)g.num_regions * tiles_per_region(g, es);
 }
 // chain prefixes are relative to the region: 30 value bits suffice up to 2^30-element regions
 bool status32(const RegionGeom& g) { return g.region_shift <= 30; }
@@ -305,6 +320,7 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
     a.next = make_spec(L, NEXT ? digit + 1 : digit);
     a.spec.flip = a.next.flip = 0;  // the sweep sees mapped keys: plain digits
     a.xf = make_xform(L);
+    a.tiles_per_region = (uint32_t)tiles_per_region(g, ES);
     a.dbg = ctx->dbg;
     a.rank_atomic = ctx->rank_atomic ? 1u : 0u;
     a.hot_lanes = (ctx->dbg & 0x20000u) ? 65u : ctx->hot_lanes;  // 0x20000: atomics whatever the skew (timing only)
@@ -328,7 +344,7 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
     if (const char* o = std::getenv("RSX_OCC")) grid = (uint64_t)ctx->num_cu * std::atoi(o);  // tuning only
     {   // static mode: workgroups per region, proportional to the region's tile count, >= 1 each
         const uint32_t NR = g.num_regions;
-        const uint64_t tpr = 1ull << (g.region_shift - log2u(TILE));
+        const uint64_t tpr = tiles_per_region(g, ES);
         const uint64_t real_tiles = (g.n + TILE - 1) / TILE;
         uint64_t cum = 0;
         for (uint32_t r = 0; r < NR; ++r) {

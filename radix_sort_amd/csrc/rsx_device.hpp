@@ -356,6 +356,7 @@ struct SweepArgs {
     void* status_clean;           // the next pass's status words: every tile zeroes its row there (null on a last pass)
     uint32_t rank_atomic;         // 1: ranks may come from returned LDS atomics (ordering self-test passed)
     uint32_t hot_lanes;           // a digit shared by this many lanes of round 0 sends the tile down the ballot path
+    uint32_t tiles_per_region;    // ceil(region length / tile): status rows per region
     uint32_t local_mask;          // static mode: regions whose workgroups all sit in one residue class of blockIdx % 8
     unsigned long long* jnext;    // [MAX_REGIONS][256] next pass's count matrix (accumulated), or null
     uint32_t* error;              // set non-zero if a bounded spin gave up
@@ -520,12 +521,10 @@ __global__ __launch_bounds__(WG, (WG == 1024 ? RSX_MINW_1024 : KPT * (ES < 4 ? 4
 __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const SweepArgs a) {
     constexpr int NWAVE = WG / WAVE;
     constexpr int TILE = WG * KPT;
-    constexpr int TILE_LOG = __builtin_ctz(TILE);
     // next-tile prefetch keeps the element registers live through the write-out: only where that fits
     // the VGPR budget without spilling (u32 x 16 keys does not at 80 VGPRs, and is VALU-bound anyway)
     constexpr bool EARLY_HOP = RSX_EARLY_HOP == 1 || (RSX_EARLY_HOP == 2 && ES <= 4);
     constexpr bool PREFETCH = RSX_PREFETCH_ALL != 0 && (RSX_PREFETCH_ALL != 3 || ES >= 12);
-    static_assert((TILE & (TILE - 1)) == 0, "tile size must be a power of two (regions are whole tiles)");
     static_assert(WG >= RADIX, "need one thread per digit");
     static_assert(TILE <= 65536 / 2, "wave counters are 16 bit");
     using E = Elem<ES>;
@@ -547,7 +546,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
     const E* __restrict__ src = static_cast<const E*>(a.src);
     S* status = static_cast<S*>(a.status);
     const uint32_t NR = a.g.num_regions;
-    const uint32_t tpr_log = a.g.region_shift - TILE_LOG;  // log2(tiles per region)
+    const uint32_t tpr = a.tiles_per_region;  // status rows per region (the last tile of a region may be partial)
     const uint64_t region_len = 1ull << a.g.region_shift;
 
     if (NEXT)
@@ -610,7 +609,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
     {
         const uint64_t rbeg = (uint64_t)home << a.g.region_shift;
         const uint64_t rlen = (a.g.n - rbeg) < region_len ? (a.g.n - rbeg) : region_len;
-        st_nt = (uint32_t)((rlen + TILE - 1) >> TILE_LOG);
+        st_nt = (uint32_t)((rlen + TILE - 1) / TILE);
     }
     // A chain whose workgroups were all verified on ONE XCD shares one L2: its status words can then
     // be plain stores that stay in that L2 (an agent-scope store writes through to memory and the
@@ -631,7 +630,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         while (alive > 0) {
             const uint64_t rbeg = (uint64_t)r << a.g.region_shift;
             const uint64_t rlen = (a.g.n - rbeg) < region_len ? (a.g.n - rbeg) : region_len;
-            const uint32_t nt = (uint32_t)((rlen + TILE - 1) >> TILE_LOG);
+            const uint32_t nt = (uint32_t)((rlen + TILE - 1) / TILE);
             if (k < nt) {
                 have = true;
                 break;
@@ -689,13 +688,13 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
             kt = __builtin_amdgcn_readfirstlane(s_misc[2]);
         }
 
-        const uint64_t tile_base = ((uint64_t)reg << a.g.region_shift) + ((uint64_t)kt << TILE_LOG);
+        const uint64_t tile_base = ((uint64_t)reg << a.g.region_shift) + (uint64_t)kt * TILE;
         const uint64_t rend = ((uint64_t)(reg + 1) << a.g.region_shift) < a.g.n ? ((uint64_t)(reg + 1) << a.g.region_shift) : a.g.n;
         const uint64_t remain = rend - tile_base;
         const bool full = remain >= (uint64_t)TILE;
         const uint32_t valid = full ? (uint32_t)TILE : (uint32_t)remain;
         const uint32_t pad = TILE - valid;  // invalid tail slots, ranked as digit 255 after all valid ones
-        const uint64_t stat_row = (((uint64_t)reg << tpr_log) + kt) * RADIX;
+        const uint64_t stat_row = ((uint64_t)reg * tpr + kt) * RADIX;
         const uint32_t seg = wave * (WAVE * KPT) + lane;
 
         // ---- load + digit + match: independent -> ILP ------------
@@ -911,7 +910,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         // behind 16 HBM loads would wait for all of them.
         const bool prefetch = static_mode && PREFETCH && st_k < st_nt;
         auto issue_next = [&]() {
-            const uint64_t tb = ((uint64_t)home << a.g.region_shift) + ((uint64_t)st_k << TILE_LOG);
+            const uint64_t tb = ((uint64_t)home << a.g.region_shift) + (uint64_t)st_k * TILE;
             const uint64_t re = ((uint64_t)(home + 1) << a.g.region_shift) < a.g.n ? ((uint64_t)(home + 1) << a.g.region_shift) : a.g.n;
             const bool fl = re - tb >= (uint64_t)TILE;
             load_tile<ES, KPT>(e, src + tb, seg, fl ? (uint32_t)TILE : (uint32_t)(re - tb), fl);
