@@ -132,6 +132,16 @@ int rsx_segmented_copy_device(rsx_ctx *ctx, const void *d_src, void *d_dst, uint
 int rsx_extract_keys_device(rsx_ctx *ctx, const void *d_src, size_t n, const rsx_layout *layout,
                             int64_t *d_keys, void *stream);
 
+/* Lower and upper bounds of `nq` 128-bit mapped-key queries in a slice that is
+ * already sorted: d_queries holds nq pairs (low 64 bits, high 64 bits) of the
+ * mapped key of radix_digits.rs:7-124 (unsigned order == sort order); d_out
+ * receives 2*nq uint64: d_out[i] = elements with key < query i, d_out[nq + i] =
+ * elements with key <= query i.  The splitter search of a multi-GPU sort asks
+ * these of every locally sorted slice (mod.rs:110-120's cursors, by search
+ * instead of by scan). */
+int rsx_bounds_device(rsx_ctx *ctx, const void *d_sorted, size_t n, const rsx_layout *layout,
+                      const uint64_t *d_queries, uint32_t nq, uint64_t *d_out, void *stream);
+
 /* -- multi-GPU from one process ------------------------------------------- */
 /* Sorts the concatenation slice 0 | slice 1 | ... | slice ndev-1 as ONE array,
  * stably and in place: slice g keeps its length n_per_dev[g] and ends up

@@ -170,6 +170,10 @@ class Context:
         self._check(self._L.rsx_segmented_copy_device(self._h, d_src, d_dst, elem_bytes, d_src_off, d_dst_off,
                                                       d_len, nseg, stream))
 
+    def bounds_device(self, d_sorted: int, n: int, d: RadixDigits, d_queries: int, nq: int, d_out: int, stream: int = 0):
+        lay = d.layout()
+        self._check(self._L.rsx_bounds_device(self._h, d_sorted, n, ctypes.byref(lay), d_queries, nq, d_out, stream))
+
     def extract_keys_device(self, d_src: int, n: int, d: RadixDigits, d_keys: int, stream: int = 0):
         lay = d.layout()
         self._check(self._L.rsx_extract_keys_device(self._h, d_src, n, ctypes.byref(lay), d_keys, stream))

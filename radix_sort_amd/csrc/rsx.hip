@@ -767,6 +767,23 @@ int rsx_extract_keys_device(rsx_ctx* ctx, const void* d_src, size_t n, const rsx
     return RSX_ERR_HIP;
 }
 
+int rsx_bounds_device(rsx_ctx* ctx, const void* d_sorted, size_t n, const rsx_layout* L, const uint64_t* d_queries,
+                      uint32_t nq, uint64_t* d_out, void* stream) try {
+    if (!ctx) return RSX_ERR_ARG;
+    if (!layout_ok(L)) return fail(ctx, RSX_ERR_ARG, "invalid rsx_layout");
+    if (nq == 0) return RSX_OK;
+    if (!d_queries || !d_out || (n && !d_sorted)) return fail(ctx, RSX_ERR_ARG, "null pointer");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(rsx_bounds_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, static_cast<const uint8_t*>(d_sorted),
+                       (uint64_t)n, L->elem_bytes, L->key_offset, L->key_bytes, L->key_kind, d_queries, nq, d_out);
+    RSX_HIP(hipGetLastError());
+    return RSX_OK;
+} catch (...) {
+    return RSX_ERR_HIP;
+}
+
 // ---- multi-GPU, one process: one exchange between two local sorts ------------------------------
 // The G slices are "chunks" in the sense of mod.rs:66-70; the result is what the reference would
 // produce on their concatenation.  Schedule: (1) every device sorts its slice; (2) the G-1 slice

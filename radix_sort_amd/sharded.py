@@ -68,6 +68,19 @@ class HipBackend:
         self.ctx.extract_keys_device(x.data_ptr(), n, d, k.data_ptr(), s)
         return k
 
+    def bounds(self, x, n: int, d: RadixDigits, q_lo: np.ndarray, q_hi: np.ndarray):
+        """(less, less_or_equal) counts of the 128-bit mapped-key queries in the sorted slice x
+        (rsx_bounds_device); numpy int64 arrays."""
+        nq = len(q_lo)
+        q = np.empty((nq, 2), dtype=np.uint64)
+        q[:, 0], q[:, 1] = q_lo, q_hi
+        dq = self.torch.from_numpy(q.view(np.int64).reshape(-1)).to(self.device)
+        out = self.torch.empty(2 * nq, dtype=self.torch.int64, device=self.device)
+        s = self.torch.cuda.current_stream().cuda_stream
+        self.ctx.bounds_device(x.data_ptr(), n, d, dq.data_ptr(), nq, out.data_ptr(), s)
+        o = out.cpu().numpy()
+        return o[:nq].copy(), o[nq:].copy()
+
     def finish(self):
         self.ctx.check(self.torch.cuda.current_stream().cuda_stream)
 
@@ -165,10 +178,7 @@ class ShardedRadixSort:
         return t.cpu().numpy()
 
     def sort_one_exchange(self, x, d: RadixDigits, n_per_rank: Optional[List[int]] = None):
-        """Same contract as `sort`; one all-to-all instead of one per digit.  Keys wider than
-        8 bytes fall back to `sort`."""
-        if d.key_bytes > 8:
-            return self.sort(x, d, n_per_rank)
+        """Same contract as `sort`; one all-to-all instead of one per digit."""
         import torch
         dist, be = self.dist, self.backend
         es, G = d.elem_bytes, self.world
@@ -183,25 +193,30 @@ class ShardedRadixSort:
         # 1. local sort (stable)
         if n_local > 1:
             be.sort(x, tmp, n_local, d)
-        keys = be.mapped_keys(x, n_local, d)  # sorted ascending (signed order == key order)
         # 2. exact splitters: for every interior boundary T_h the key K_h with
-        #    global_less(K_h) <= T_h < global_less_or_equal(K_h), found digit by digit (256-way)
+        #    global_less(K_h) <= T_h < global_less_or_equal(K_h), found digit by digit (256-way);
+        #    keys are 128-bit (lo, hi) mapped keys, counted by binary search in every sorted slice
         targets = bounds[1:-1]  # G-1 boundaries
         nb = len(targets)
-        bits = 8 * d.key_bytes
-        prefix = np.zeros(nb, dtype=np.uint64)
+        pre_lo = np.zeros(nb, dtype=np.uint64)
+        pre_hi = np.zeros(nb, dtype=np.uint64)
+        j256 = np.arange(256, dtype=np.uint64)
         for digit in range(d.key_bytes - 1, -1, -1):
-            shift = np.uint64(8 * digit)
-            cand = prefix[:, None] | (np.arange(256, dtype=np.uint64)[None, :] << shift)  # [nb][256]
-            less = torch.searchsorted(keys, torch.from_numpy(_signed64(cand.reshape(-1))).to(keys.device))
-            gl = self._all_reduce_sum(less.cpu().numpy(), x.device).reshape(nb, 256)
+            lo = np.repeat(pre_lo[:, None], 256, axis=1)
+            hi = np.repeat(pre_hi[:, None], 256, axis=1)
+            if digit < 8:
+                lo |= j256[None, :] << np.uint64(8 * digit)
+            else:
+                hi |= j256[None, :] << np.uint64(8 * (digit - 8))
+            less, _ = be.bounds(x, n_local, d, lo.reshape(-1), hi.reshape(-1))
+            gl = self._all_reduce_sum(less, x.device).reshape(nb, 256)
             # largest candidate whose global "less" count does not exceed the target
-            j = (gl <= targets[:, None]).sum(axis=1) - 1  # gl[:,0] counts keys < prefix: always <= target
-            prefix |= j.astype(np.uint64) << shift
-        maxkey = np.uint64((1 << bits) - 1) if bits < 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
-        k_lo = torch.from_numpy(_signed64(prefix)).to(keys.device)
-        less_me = torch.searchsorted(keys, k_lo).cpu().numpy().astype(np.int64)  # elements < K_h on this rank
-        leq_me = torch.searchsorted(keys, k_lo, right=True).cpu().numpy().astype(np.int64)  # elements <= K_h
+            j = ((gl <= targets[:, None]).sum(axis=1) - 1).astype(np.uint64)  # gl[:,0] counts keys < prefix: always <= target
+            if digit < 8:
+                pre_lo |= j << np.uint64(8 * digit)
+            else:
+                pre_hi |= j << np.uint64(8 * (digit - 8))
+        less_me, leq_me = be.bounds(x, n_local, d, pre_lo, pre_hi) if nb else (np.zeros(0, np.int64), np.zeros(0, np.int64))
         mine = np.stack([less_me, leq_me]).astype(np.int64)  # [2][nb]
         allm = [torch.zeros(2 * nb, dtype=torch.int64) for _ in range(G)]
         src = torch.from_numpy(mine.reshape(-1))
@@ -220,7 +235,6 @@ class ShardedRadixSort:
         send_counts = np.diff(split[self.rank])  # to each destination
         recv_counts = split[:, self.rank + 1] - split[:, self.rank]  # from each source
         assert send_counts.sum() == n_local and recv_counts.sum() == n_local, (send_counts, recv_counts)
-        del keys
         # 3. the one exchange
         if self.host_staged and x.is_cuda:
             rc = torch.empty(n_local * es, dtype=torch.uint8)

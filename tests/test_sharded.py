@@ -63,6 +63,16 @@ class OracleBackend:
         u = pad.view("<u8").reshape(n)
         return self.torch.from_numpy((u ^ np.uint64(1 << 63)).view(np.int64).copy())
 
+    def bounds(self, x, n, d, q_lo, q_hi):
+        lay = self.orc.Layout(d.elem_bytes, d.key_offset, d.key_bytes, d.key_kind)
+        cols = self.orc.numpy_mapped_key_columns(x.numpy()[: n * d.elem_bytes], lay)
+        keys = [int.from_bytes(bytes(r), "little") for r in cols]  # sorted ascending (python ints: 128-bit safe)
+        import bisect
+        qs = [int(l) | (int(h) << 64) for l, h in zip(q_lo, q_hi)]
+        less = np.array([bisect.bisect_left(keys, q) for q in qs], dtype=np.int64)
+        leq = np.array([bisect.bisect_right(keys, q) for q in qs], dtype=np.int64)
+        return less, leq
+
     def finish(self):
         pass
 
