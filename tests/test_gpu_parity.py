@@ -230,13 +230,45 @@ def test_skewed_and_degenerate_large(rs, torch, ctx):
         _full_size(rs, torch, ctx, "(u32,u32)", (1 << 24) + 12345, gen, param)
 
 
-def test_more_than_2pow30_elements_uses_64bit_status(rs, torch, ctx):
-    """n > 2^30 switches the look-back words to 64 bit; all-equal keys push one digit's
-    prefix past 2^30."""
+def test_more_than_2pow30_elements(rs, torch, ctx):
+    """n > 2^30: 64-bit element indices everywhere; all-equal keys push one digit's bucket past 2^30."""
     n = (1 << 30) + (1 << 20) + 77
     _full_size(rs, torch, ctx, "u8", n, rs.GEN_UNIFORM)
     # all-equal u8 key + 7-byte payload (= original index, wide enough not to wrap)
     _full_size(rs, torch, ctx, "(u8,[u8;7])", n, rs.GEN_CONSTANT, param=3.0)
+
+
+def test_64bit_status_words_single_region():
+    """Regions longer than 2^30 elements switch the look-back words to 64 bit.  With the default
+    8-16 regions that takes n > 2^33; RSX_REGIONS=1 (one chain over everything) reaches it at
+    n > 2^30.  Child process: the knob is read once per process."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+sys.path.insert(0, os.getcwd())
+import torch, radix_sort_amd as rs
+ctx = rs.default_context(0)
+n = (1 << 30) + (1 << 20) + 77
+for name, d, gen, param in (("u8", rs.PRIMITIVES["u8"], rs.GEN_UNIFORM, 0.0),
+                            ("(u8,[u8;7])", rs.RadixDigits(8, 0, 1, 0), rs.GEN_CONSTANT, 3.0)):
+    x = torch.empty(n * d.elem_bytes, dtype=torch.uint8, device="cuda")
+    tmp = torch.empty_like(x)
+    out = torch.zeros(3, dtype=torch.int64, device="cuda")
+    ctx.generate_device(x.data_ptr(), n, d, gen, 7, param)
+    ctx.verify_device(x.data_ptr(), n, d, out.data_ptr()); torch.cuda.synchronize()
+    before = out[1].item()
+    rs.radix_sort(x, digits=d, tmp=tmp); ctx.check()
+    ctx.verify_device(x.data_ptr(), n, d, out.data_ptr()); torch.cuda.synchronize()
+    assert out[0].item() == 0 and out[1].item() == before and out[2].item() == 0, (name, out.tolist())
+    del x, tmp
+print("STATUS64 OK")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, RSX_REGIONS="1", RSX_DEBUG="0x200"),
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "STATUS64 OK" in out.stdout, out.stdout + out.stderr[-3000:]
+    assert "regions=1" in out.stderr
 
 
 def test_verify_detects_errors(rs, torch, ctx):
