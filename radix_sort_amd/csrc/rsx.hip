@@ -330,11 +330,15 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
     const size_t lds = (size_t)TILE * ES + (SWEEP_WG / WAVE) * RADIX * ((RSX_WIDE_CNT && ES <= 4 && KPT >= 16 && SWEEP_WG <= 512) ? sizeof(uint32_t) : sizeof(uint16_t)) +
                        (NEXT ? (size_t)g.num_regions * RADIX * sizeof(uint32_t) : 0) + 64;
     auto kern = rsx_sweep_kernel<ES, KPT, SWEEP_WG, S, XF, NEXT>;
-    static int occ = 0;  // per instantiation: resident workgroups per CU for this kernel
-    if (occ == 0) {
+    // resident workgroups per CU for this kernel at this LDS size (the count matrix of the next pass
+    // makes the LDS size depend on the number of regions): cached per instantiation and thread
+    thread_local size_t occ_lds = ~(size_t)0;
+    thread_local int occ = 0;
+    if (occ == 0 || occ_lds != lds) {
         int o = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kern, SWEEP_WG, lds) != hipSuccess || o < 1) o = 2;
         occ = o;
+        occ_lds = lds;
     }
     // persistent workgroups; correctness does not need them co-resident (a workgroup only
     // ever waits for tiles whose tickets were drawn earlier, by workgroups already running)
