@@ -404,3 +404,32 @@ def test_sharded_argument_errors(rs, torch):
         rs.radix_sort_sharded([a, b], d, ctxs=[c, c])
     with pytest.raises(ValueError):
         rs.radix_sort_sharded([a, b], d, ctxs=[c])
+
+
+def test_two_contexts_two_streams_concurrently(rs, torch, orc):
+    """Two sorts in flight at once on one device (separate contexts and streams): their sweep kernels
+    compete for the CUs, so the roll call of either may fail and fall back to ticketed tiles -- results
+    must not care."""
+    d = _digits(rs, "u32")
+    lay = orc.Layout(*util.TYPES["u32"])
+    n = 6_000_001
+    raws = [util.make_input("u32", n, "uniform", seed=900 + i) for i in range(2)]
+    want = [orc.sort_parallel(r, lay, 8) for r in raws]
+    ctxs = [rs.Context(torch.cuda.current_device()) for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    xs = [torch.from_numpy(r.copy()).cuda() for r in raws]
+    tmps = [torch.empty_like(x) for x in xs]
+    torch.cuda.synchronize()
+    for rep in range(6):
+        for i in range(2):
+            xs[i].copy_(torch.from_numpy(raws[i]).cuda(), non_blocking=False)
+        torch.cuda.synchronize()
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                rs.radix_sort(xs[i], digits=d, tmp=tmps[i], ctx=ctxs[i])
+        for i in range(2):
+            streams[i].synchronize()
+            ctxs[i].check(streams[i].cuda_stream)
+            assert np.array_equal(xs[i].cpu().numpy(), want[i]), (rep, i)
+    for c in ctxs:
+        c.close()
