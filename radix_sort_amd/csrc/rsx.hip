@@ -42,7 +42,6 @@ struct rsx_ctx {
     void* host_buf[2] = {nullptr, nullptr};
     size_t host_bytes = 0;
     int num_cu = 256;
-    uint32_t stagger = 1;  // RSX_STAGGER env (tuning)
     uint32_t pass_index = 0;   // of the sweep being launched within its sort (selects the status half)
     bool pass_last = true;     // no pass follows: nothing to clean
     bool rank_atomic = false;  // LDS atomic ordering self-test passed (set when the workspace is first made)
@@ -324,8 +323,6 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
     a.dbg = ctx->dbg;
     a.rank_atomic = ctx->rank_atomic ? 1u : 0u;
     a.hot_lanes = (ctx->dbg & 0x20000u) ? 65u : ctx->hot_lanes;  // 0x20000: atomics whatever the skew (timing only)
-    a.stagger = ctx->stagger;
-    a.num_cu = (uint32_t)ctx->num_cu;
     a.dbg_cnt = reinterpret_cast<unsigned long long*>(ctx->aux + OFF_DBG);
     const size_t lds = (size_t)TILE * ES + (SWEEP_WG / WAVE) * RADIX * ((RSX_WIDE_CNT && ES <= 4 && KPT >= 16 && SWEEP_WG <= 512) ? sizeof(uint32_t) : sizeof(uint16_t)) +
                        (NEXT ? (size_t)g.num_regions * RADIX * sizeof(uint32_t) : 0) + 64;
@@ -492,7 +489,6 @@ int rsx_ctx_create(int device, rsx_ctx** out) try {
     ctx->device = device;
     if (const char* dbg = std::getenv("RSX_DEBUG")) ctx->dbg = (uint32_t)std::strtoul(dbg, nullptr, 0);
     if (const char* h = std::getenv("RSX_HOT")) ctx->hot_lanes = (uint32_t)std::strtoul(h, nullptr, 0);
-    if (const char* sg = std::getenv("RSX_STAGGER")) ctx->stagger = (uint32_t)std::strtoul(sg, nullptr, 0);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
         ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;

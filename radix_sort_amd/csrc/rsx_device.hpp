@@ -364,8 +364,6 @@ struct SweepArgs {
     DigitSpec next;               // next pass's digit (when jnext != null)
     KeyXform xf;                  // signed/float key map applied on load (XF & 1) / undone on store (XF & 2)
     uint32_t dbg;                 // timing-only ablation switches (0 in production)
-    uint32_t stagger;             // start delay between the workgroups sharing a CU (x 512 cycles)
-    uint32_t num_cu;
     unsigned long long* dbg_cnt;  // [8] diagnostic counters (dbg & 0x100)
 };
 
@@ -391,9 +389,6 @@ struct SweepArgs {
 #endif
 #ifndef RSX_MINW
 #define RSX_MINW 6
-#endif
-#ifndef RSX_MATCH_ILP
-#define RSX_MATCH_ILP 2
 #endif
 #ifndef RSX_NUM_SGPR
 #define RSX_NUM_SGPR 102
@@ -424,9 +419,6 @@ struct SweepArgs {
 #endif
 #ifndef RSX_DPP_SCAN
 #define RSX_DPP_SCAN 2  // 0 off, 1 on, 2 = where measured faster (elements of <= 4 bytes)
-#endif
-#ifndef RSX_PRIO_BAL
-#define RSX_PRIO_BAL 0
 #endif
 #ifndef RSX_PREFETCH_ALL
 #define RSX_PREFETCH_ALL 3  // 0 off, 1 before/after the look-back, 2 behind it, 3 = 2 where measured faster (>= 12-byte elements)
@@ -698,8 +690,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         const uint32_t seg = wave * (WAVE * KPT) + lane;
 
         // ---- load + digit + match: independent -> ILP ------------
-        if (RSX_PRIO_BAL && wave >= NWAVE / 2) __builtin_amdgcn_s_setprio(1);  // the younger half otherwise trails the older
-        else __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
         if (!preloaded) load_tile<ES, KPT>(e, src + tile_base, seg, valid, full);
 #ifdef RSX_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // diagnostic build: split load wait from match
