@@ -178,6 +178,9 @@ def main():
     ap.add_argument("--extra", default=",".join(EXTRA_DEFAULT),
                     help="comma list of further workloads measured (3 steps each) and reported under 'extra' at N=1; '' = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="N>1 collectives: nccl (= RCCL over xGMI, the measured path); gloo only to rehearse the N>1 code "
+                         "path on a box with fewer GPUs than ranks (ranks then share devices, exchange staged through the host)")
     ap.add_argument("--exchange", default="one", choices=["one", "per-pass"],
                     help="multi-GPU schedule: one all-to-all (default) or one per digit pass (the reference's loop with chunk == GPU)")
     args = ap.parse_args()
@@ -190,6 +193,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if args.backend == "gloo":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     ctx = rs.default_context(local_rank)
     t, logn, gen, param, desc = WORKLOADS[args.workload]
@@ -238,7 +243,10 @@ def main():
     # ---- N > 1: one slice per rank, per-pass bucket exchange over RCCL ---------------------
     import torch.distributed as dist
     from radix_sort_amd.sharded import ShardedRadixSort
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group("gloo")
     sorter = ShardedRadixSort()
     nbytes = n * d.elem_bytes
     stream = torch.cuda.current_stream().cuda_stream
@@ -266,7 +274,7 @@ def main():
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     # untimed global order check: local order + boundaries between ranks
     out = torch.zeros(3, dtype=torch.int64, device="cuda")
@@ -285,8 +293,8 @@ def main():
                        "n_keys_per_gpu": n, "elem_bytes": d.elem_bytes, "passes": d.key_bytes, "radix_bits": 8,
                        "generator": gen,
                        "exchange": ("local sort + 256-way splitter search (1 all-reduce per digit) + ONE all-to-all-v + "
-                                    "local sort (RCCL)") if args.exchange == "one" else
-                                   "per-pass all-gather(256 x u64) + all-to-all-v (RCCL)"},
+                                    "local sort (%s)" % ("RCCL" if args.backend == "nccl" else "gloo, host-staged: rehearsal only")) if args.exchange == "one" else
+                                   "per-pass all-gather(256 x u64) + all-to-all-v (%s)" % ("RCCL" if args.backend == "nccl" else "gloo, host-staged: rehearsal only")},
             "roofline": {"bound": "hbm", "achieved": d.key_bytes * 2 * total * d.elem_bytes / ms / 1e6,
                          "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
                          "frac": d.key_bytes * 2 * total * d.elem_bytes / ms / 1e6 / (HBM_PEAK_GBPS * world),
