@@ -124,7 +124,8 @@ bool aligned(const void* p, uint32_t a) { return (reinterpret_cast<uintptr_t>(p)
 // Keys per thread by element size.  Tiles need not be powers of two (the last tile of a region is
 // partial anyway); bigger tiles mean longer output runs per digit (fewer partial cache lines, the
 // memory system's real cost here) and fewer look-backs per key, as long as two or three workgroups
-// still fit a CU: u32 28 x 512 = 14336 keys (56 KiB), u64 12 x 512 (48 KiB), 16-byte 5 x 512 (40 KiB).
+// still fit a CU: u32 28 x 512 = 14336 keys (56 KiB), u64 12 x 512 (48 KiB), 16-byte 5 x 512 (40 KiB),
+// 24/32-byte 3 x 512 (36/48 KiB).
 // Measured against 16 / 8 / 4: 1B u32 117 -> 136, 1B u64 32 -> 34.9, 128M (u64,u64) 17.3 -> 18 Gkeys/s.
 #ifndef RSX_KPT4
 #define RSX_KPT4 28
@@ -139,7 +140,7 @@ bool aligned(const void* p, uint32_t a) { return (reinterpret_cast<uintptr_t>(p)
 #define RSX_KPT16 5
 #endif
 #ifndef RSX_KPT32
-#define RSX_KPT32 2
+#define RSX_KPT32 3
 #endif
 #ifndef RSX_WG8
 #define RSX_WG8 512
