@@ -125,7 +125,7 @@ bool aligned(const void* p, uint32_t a) { return (reinterpret_cast<uintptr_t>(p)
 // partial anyway); bigger tiles mean longer output runs per digit (fewer partial cache lines, the
 // memory system's real cost here) and fewer look-backs per key, as long as two or three workgroups
 // still fit a CU: u32 28 x 512 = 14336 keys (56 KiB), u64 12 x 512 (48 KiB), 16-byte 5 x 512 (40 KiB),
-// 24/32-byte 3 x 512 (36/48 KiB).
+// 12-byte 10 x 512 (60 KiB), 24/32-byte 3 x 512 (36/48 KiB).
 // Measured against 16 / 8 / 4: 1B u32 117 -> 136, 1B u64 32 -> 34.9, 128M (u64,u64) 17.3 -> 18 Gkeys/s.
 #ifndef RSX_KPT4
 #define RSX_KPT4 28
@@ -139,13 +139,16 @@ bool aligned(const void* p, uint32_t a) { return (reinterpret_cast<uintptr_t>(p)
 #ifndef RSX_KPT16
 #define RSX_KPT16 5
 #endif
+#ifndef RSX_KPT12
+#define RSX_KPT12 10
+#endif
 #ifndef RSX_KPT32
 #define RSX_KPT32 3
 #endif
 #ifndef RSX_WG8
 #define RSX_WG8 512
 #endif
-constexpr int kpt_for(int es) { return es <= 4 ? RSX_KPT4 : es == 8 ? RSX_KPT8 : es <= 16 ? RSX_KPT16 : RSX_KPT32; }
+constexpr int kpt_for(int es) { return es <= 4 ? RSX_KPT4 : es == 8 ? RSX_KPT8 : es == 12 ? RSX_KPT12 : es == 16 ? RSX_KPT16 : RSX_KPT32; }
 constexpr int wg_for(int es) { return es <= 4 ? RSX_WG4 : es == 8 ? RSX_WG8 : 512; }
 constexpr uint32_t tile_elems(int es) { return wg_for(es) * kpt_for(es); }
 
