@@ -625,6 +625,21 @@ int rsx_sort_device(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const rsx
     // count phase of pass 0 (mod.rs:90-109); later passes are counted by the sweep before them
     rc = hist_dispatch(ctx, d_data, geom, L, 0, J_of(ctx, 0), st);
     if (rc) return rc;
+    if (L->elem_bytes == 1 && !(ctx->dbg & 0x40000u)) {
+        // u8 / i8: the element is its digit, so the 256 counts ARE the sorted array (same bytes as
+        // the pass + copy-back of mod.rs:121-174 would leave): write the runs, skip scatter and copy
+        uint64_t* totals = reinterpret_cast<uint64_t*>(J_of(ctx, 1));
+        rc = launch_prefix(ctx, geom, J_of(ctx, 0), nullptr, totals, st);
+        if (rc) return rc;
+        LaunchTimer lt(ctx, RSX_PROF_OTHER, st);
+        const uint64_t chunks = (n + 15) / 16;
+        uint64_t blocks = (chunks + 255) / 256;
+        if (blocks > (uint64_t)ctx->num_cu * 16) blocks = (uint64_t)ctx->num_cu * 16;
+        hipLaunchKernelGGL(rsx_expand_bytes_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, static_cast<uint8_t*>(d_data),
+                           (uint64_t)n, totals, L->key_kind == RSX_KEY_SIGNED ? 0x80u : 0u);
+        RSX_HIP(hipGetLastError());
+        return RSX_OK;
+    }
     // pass loop with ping-pong (mod.rs:84-89)
     for (uint32_t d = 0; d < D; ++d) {
         const void* src = (d % 2 == 0) ? d_data : d_tmp;

@@ -1065,6 +1065,55 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
     }
 }
 
+// ------------------------------------------------------------ one-byte elements --
+// An element that IS its one-byte key (u8, i8) is fully described by its digit: the sorted array is
+// the 256 counts written out as runs (counting sort: one read of the data, one write, no scatter).
+// `counts` are by mapped digit (the count kernel maps signed keys); byte = mapped value ^ xor_mask.
+__global__ __launch_bounds__(256) void rsx_expand_bytes_kernel(uint8_t* __restrict__ dst, uint64_t n,
+                                                               const uint64_t* __restrict__ counts,
+                                                               uint32_t xor_mask) {
+    __shared__ uint64_t start[RADIX + 1];
+    __shared__ uint64_t wsum[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint64_t x = counts[tid];
+    const uint64_t c = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t y = __shfl_up(x, o);
+        if (lane >= (uint32_t)o) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    uint64_t wb = 0;
+    for (uint32_t w = 0; w < wave; ++w) wb += wsum[w];
+    start[tid] = wb + x - c;
+    if (tid == RADIX - 1) start[RADIX] = wb + x;
+    __syncthreads();
+    const bool wide = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;  // 16-byte stores need the alignment
+    const uint64_t chunks = (n + 15) / 16;
+    for (uint64_t ch = (uint64_t)blockIdx.x * blockDim.x + tid; ch < chunks; ch += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t p0 = ch * 16;
+        uint32_t lo = 0, hi = RADIX;  // last v with start[v] <= p0
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) / 2;
+            if (start[mid] <= p0) lo = mid;
+            else hi = mid;
+        }
+        uint32_t v = lo;
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            while (v < RADIX - 1 && start[v + 1] <= p0 + k) ++v;  // empty digits are stepped over
+            w[k / 4] |= ((v ^ xor_mask) & 0xFFu) << (8 * (k % 4));
+        }
+        if (wide && p0 + 16 <= n) {
+            *reinterpret_cast<uint4*>(dst + p0) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+            for (int k = 0; k < 16 && p0 + k < n; ++k) dst[p0 + k] = (uint8_t)(w[k / 4] >> (8 * (k % 4)));
+        }
+    }
+}
+
 // ------------------------------------------------------------ segmented copy --
 // One workgroup walks segments grid-stride; segment copy is element-granular.
 template <int ES>

@@ -291,7 +291,8 @@ def test_verify_detects_errors(rs, torch, ctx):
                                          ("0x10000", "ranks by ballots only"),
                                          ("0x20000", "ranks by returned LDS atomics whatever the skew"),
                                          ("0x8000", "agent-scope status stores even on verified single-XCD chains"),
-                                         ("0x4000", "no XCD-major workgroup numbering")])
+                                         ("0x4000", "no XCD-major workgroup numbering"),
+                                         ("0x40000", "one-byte elements through the general pass instead of the counting path")])
 def test_alternative_kernel_paths_match(orc, switch, what):
     """Every fallback / alternative path of the sweep kernel (selected by an RSX_DEBUG bit) must give
     the same bytes as the default path.  Runs in a child process: the switches are read once per
@@ -306,7 +307,7 @@ import radix_sort_amd as rs
 from oracle import oracle
 ctx = rs.default_context(0)
 for t, n, dist in (("u32", 3000001, "uniform"), ("(u64,u64)", 700001, "zipf"), ("f32", 1500000, "uniform"),
-                   ("u8", 5000000, "uniform"), ("(u8,[u8;7])", 2000003, "two"), ("(u32,u32)", 1000001, "step16"),
+                   ("u8", 5000000, "uniform"), ("i8", 3000001, "zipf"), ("(u8,[u8;7])", 2000003, "two"), ("(u32,u32)", 1000001, "step16"),
                    ("(i16,u16)", 1234567, "equal"), ("u64", 2000001, "lowbyte"), ("(u32,[u8;8])", 500009, "zipf")):
     d = rs.RadixDigits(*util.TYPES[t])
     raw = util.make_input(t, n, dist, seed=31)
