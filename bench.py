@@ -61,7 +61,7 @@ def gen_id(rs, name):
             "reversed": rs.GEN_REVERSED}[name]
 
 
-def run_single(rs, torch, ctx, wl, steps, warmup, seed0=0x5EED0000, profile=True):
+def run_single(rs, torch, ctx, wl, steps, warmup, seed0=0x5EED0000, profile=True, check=True):
     """Times `steps` sorts of `steps` different batches on the current device. Returns dict."""
     t, logn, gen, param, _ = WORKLOADS[wl]
     d = digits_for(rs, t)
@@ -102,13 +102,13 @@ def run_single(rs, torch, ctx, wl, steps, warmup, seed0=0x5EED0000, profile=True
                 prof_tot[kname][0] += pr[kname][0]
                 prof_tot[kname][1] += pr[kname][1]
         done += k
-    ctx.check()
+    if check:
+        ctx.check()
     # untimed sanity: last batch is sorted and is a permutation of its input
     out = torch.zeros(3, dtype=torch.int64, device="cuda")
     ctx.verify_device(bufs[k - 1].data_ptr(), n, d, out.data_ptr(), stream)
     v = out.cpu().tolist()
-    if not os.environ.get("RSX_DEBUG"):  # ablation switches produce wrong output by design
-        assert v[0] == 0 and v[2] == 0, f"bench output not sorted/stable: {v}"
+    assert not check or (v[0] == 0 and v[2] == 0), f"bench output not sorted/stable: {v}"
     del bufs, tmp
     torch.cuda.empty_cache()
     ms = total_ms / steps
@@ -174,16 +174,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2-256m-u32", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: c2-256m-u32 (configs[1]) at N=1; c4-slice-512m-u32 per GPU at N>1 (configs[3]: 2^32 keys at N=8)")
     ap.add_argument("--extra", default=",".join(EXTRA_DEFAULT),
-                    help="comma list of further workloads measured (3 steps each) and reported under 'extra' at N=1; '' = none")
+                    help="comma list of further workloads measured with the same --steps/--warmup and reported under 'extra' at N=1; '' = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N>1 collectives: nccl (= RCCL over xGMI, the measured path); gloo only to rehearse the N>1 code "
                          "path on a box with fewer GPUs than ranks (ranks then share devices, exchange staged through the host)")
-    ap.add_argument("--exchange", default="one", choices=["one", "per-pass"],
-                    help="multi-GPU schedule: one all-to-all (default) or one per digit pass (the reference's loop with chunk == GPU)")
+    ap.add_argument("--exchange", default="first", choices=["first", "one", "per-pass"],
+                    help="multi-GPU schedule: 'first' = partition by the top digit, ONE all-to-all, one local sort (default); "
+                         "'one' = local sort, one all-to-all, local sort; 'per-pass' = one all-to-all per digit pass "
+                         "(the reference's loop with chunk == GPU, the north star's wording)")
     args = ap.parse_args()
+    if args.workload is None:
+        args.workload = "c2-256m-u32" if args.gpus <= 1 else "c4-slice-512m-u32"
 
     import torch
     import radix_sort_amd as rs
@@ -227,10 +232,12 @@ def main():
         extra = {}
         for wl in [w for w in args.extra.split(",") if w and w != args.workload]:
             try:
-                r = run_single(rs, torch, ctx, wl, 3, 1)
+                r = run_single(rs, torch, ctx, wl, args.steps, args.warmup)
                 extra[wl] = {k: r[k] for k in ("n", "type", "ms_per_sort", "gkeys_per_s", "algorithmic_gbps",
                                                "frac_of_hbm_peak") if k in r}
                 extra[wl]["sweep_gbps"] = r.get("sweep_gbps")
+                extra[wl]["sweep_frac_of_hbm_peak"] = (r.get("sweep_gbps") or 0.0) / HBM_PEAK_GBPS
+                extra[wl]["steps"] = args.steps
             except Exception as e:  # noqa: BLE001  (an extra must never kill the headline)
                 extra[wl] = {"error": repr(e)}
         if extra:
@@ -257,14 +264,19 @@ def main():
     def fill(i, b):
         ctx.generate_device(b.data_ptr(), n, d, gen_id(rs, gen), 0x5EED0000 + i, param, rank * n, stream)
 
-    run = (lambda b: sorter.sort_one_exchange(b, d, n_per_rank)) if args.exchange == "one" else \
-          (lambda b: sorter.sort(b, d, n_per_rank))
+    run = {"first": lambda b: sorter.sort_exchange_first(b, d, n_per_rank),
+           "one": lambda b: sorter.sort_one_exchange(b, d, n_per_rank),
+           "per-pass": lambda b: sorter.sort(b, d, n_per_rank)}[args.exchange]
     wbuf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
     for i in range(args.warmup):
         fill(1000 + i, wbuf)
         run(wbuf)
     for i in range(pool):
         fill(i, bufs[i])
+    # multiset checksum of the last batch before it is sorted (sum over ranks, compared after)
+    out = torch.zeros(3, dtype=torch.int64, device="cuda")
+    ctx.verify_device(bufs[-1].data_ptr(), n, d, out.data_ptr(), stream)
+    sum_before = out[1:2].clone()
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -274,13 +286,33 @@ def main():
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+    cdev = "cuda" if args.backend == "nccl" else "cpu"
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cdev)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    # untimed global order check: local order + boundaries between ranks
-    out = torch.zeros(3, dtype=torch.int64, device="cuda")
+    # untimed global check of the last batch: (a) every rank's slice in order and stable, (b) the multiset
+    # unchanged (checksums all-reduced), (c) order across rank boundaries: last key of rank r <= first key of r+1
     ctx.verify_device(bufs[-1].data_ptr(), n, d, out.data_ptr(), stream)
     torch.cuda.synchronize()
-    assert out[0].item() == 0, "sharded bench output not sorted"
+    assert out[0].item() == 0 and out[2].item() == 0, f"rank {rank}: slice not sorted / not stable: {out.tolist()}"
+    sums = torch.stack([sum_before[0], out[1]]).to(cdev)
+    dist.all_reduce(sums)  # int64 wrap-around == the checksum's arithmetic mod 2^64
+    assert sums[0].item() == sums[1].item(), "multiset checksum changed across the exchange"
+    es = d.elem_bytes
+    edge = torch.cat([bufs[-1][:es], bufs[-1][(n - 1) * es:n * es]]).cpu()
+
+    def mapped(e):  # order-preserving integer of one element's key (radix_digits.rs via RadixDigits.get_digit)
+        return sum(d.get_digit(bytes(e.tolist()), i) << (8 * i) for i in range(d.key_bytes))
+    def limbs(k):  # 128-bit key as four 32-bit limbs, most significant first (int64 tensors carry them)
+        return [(k >> s) & 0xFFFFFFFF for s in (96, 64, 32, 0)]
+    mine = torch.tensor(limbs(mapped(edge[:es])) + limbs(mapped(edge[es:])), dtype=torch.int64)
+    allk = [torch.zeros(8, dtype=torch.int64, device=cdev) for _ in range(world)]
+    dist.all_gather(allk, mine.to(cdev))
+    keys = []
+    for t in allk:
+        a = [int(v) for v in t.cpu().tolist()]
+        keys.append((a[0] << 96 | a[1] << 64 | a[2] << 32 | a[3], a[4] << 96 | a[5] << 64 | a[6] << 32 | a[7]))
+    for r in range(world - 1):
+        assert keys[r][1] <= keys[r + 1][0], f"order broken between rank {r} and {r + 1}"
     ms = el.item() * 1e3 / args.steps
     total = n * world
     if rank == 0:
@@ -292,9 +324,12 @@ def main():
             "config": {"workload": f"{args.workload} per GPU x {world}: {desc}", "n_keys": total,
                        "n_keys_per_gpu": n, "elem_bytes": d.elem_bytes, "passes": d.key_bytes, "radix_bits": 8,
                        "generator": gen,
-                       "exchange": ("local sort + 256-way splitter search (1 all-reduce per digit) + ONE all-to-all-v + "
-                                    "local sort (%s)" % ("RCCL" if args.backend == "nccl" else "gloo, host-staged: rehearsal only")) if args.exchange == "one" else
-                                   "per-pass all-gather(256 x u64) + all-to-all-v (%s)" % ("RCCL" if args.backend == "nccl" else "gloo, host-staged: rehearsal only")},
+                       "exchange": {"first": "partition by the top digit + all-gather(256 x u64) + exact cuts inside boundary buckets + "
+                                             "ONE all-to-all-v + one local sort",
+                                    "one": "local sort + 256-way splitter search (1 all-reduce per digit) + ONE all-to-all-v + local sort",
+                                    "per-pass": "per-pass all-gather(256 x u64) + all-to-all-v"}[args.exchange] +
+                                   (" (RCCL)" if args.backend == "nccl" else " (gloo, host-staged: rehearsal only)"),
+                       "verified": "slices sorted and stable, multiset checksum all-reduced, rank-boundary keys in order"},
             "roofline": {"bound": "hbm", "achieved": d.key_bytes * 2 * total * d.elem_bytes / ms / 1e6,
                          "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
                          "frac": d.key_bytes * 2 * total * d.elem_bytes / ms / 1e6 / (HBM_PEAK_GBPS * world),

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RSX_VERSION 100 /* 0.1.0 */
+#define RSX_VERSION 200 /* 0.2.0 */
 
 /* status codes */
 enum {
@@ -33,7 +33,8 @@ enum {
     RSX_ERR_HIP = -3,         /* a HIP runtime call failed; see rsx_last_error */
     RSX_ERR_NOMEM = -4,       /* device workspace allocation failed */
     RSX_ERR_NODEVICE = -5,    /* no gfx950-class device / wrong device */
-    RSX_ERR_WORKSPACE = -6,   /* workspace not reserved while growth is forbidden */
+    RSX_ERR_WORKSPACE = -6,   /* the call would have to allocate while its stream is being captured:
+                                 rsx_ctx_reserve first */
     RSX_ERR_INTERNAL = -7     /* a bounded device-side wait gave up (protocol error); results invalid */
 };
 
@@ -60,7 +61,11 @@ typedef struct rsx_layout {
     uint32_t key_kind;
 } rsx_layout;
 
-typedef struct rsx_ctx rsx_ctx; /* owns device workspace; one in-flight call per ctx */
+/* Owns the device workspace of its sorts.  Any number of threads may call into one context (calls
+ * are serialised by a mutex) and its calls may name different streams: work enqueued on a stream
+ * other than the context's previous one first waits, on the device, for that previous work (the
+ * workspace belongs to one sort at a time).  Use one context per stream to run sorts concurrently. */
+typedef struct rsx_ctx rsx_ctx;
 
 /* -- context ------------------------------------------------------------- */
 /* Binds a context to HIP device `device` (-1 = current device). */
@@ -75,8 +80,38 @@ int rsx_ctx_reserve(rsx_ctx *ctx, size_t n, const rsx_layout *layout);
 /* Synchronises `stream` and reports RSX_ERR_INTERNAL if any kernel of this
  * context flagged a device-side protocol error since the last check (the
  * reference panics on worker failure, mod.rs:106; across a C ABI that becomes
- * a status).  rsx_sort_host calls it itself. */
+ * a status), then clears the condition.  The error word is host-visible, so a
+ * pending error also fails the NEXT rsx_sort_device / rsx_partition_device on
+ * the context without any synchronisation; callers of the stream-ordered entry
+ * points should still call this at their own sync point -- it is the only way
+ * to learn that the sort just enqueued went wrong.  rsx_sort_host and
+ * rsx_sort_sharded check by themselves. */
 int rsx_ctx_check(rsx_ctx *ctx, void *stream);
+/* Alternative code paths of the sweep kernel; every one gives the same bytes (they exist as
+ * fall-backs that the library selects itself when a device self-test fails, and are exposed so
+ * that callers and tests can force them). */
+enum {
+    RSX_OPT_TILE_SCHEDULE = 1, /* 0 (default): static tile assignment behind a start-up roll call, tickets if
+                                  it fails; 1: ticketed tiles always */
+    RSX_OPT_RANKING = 2,       /* 0 (default): ranks from returned LDS atomics where the device's ordering
+                                  self-test passed and the tile is not skewed, wave ballots otherwise;
+                                  1: ballots only; 2: LDS atomics whatever the skew */
+    RSX_OPT_STATUS_SCOPE = 3,  /* 0 (default): look-back status words of a verified single-XCD chain stay in
+                                  that XCD's L2; 1: agent-scope stores everywhere */
+    RSX_OPT_XCD_MAJOR = 4,     /* 1 (default): workgroups numbered XCD-major; 0: by blockIdx */
+    RSX_OPT_BYTE_COUNTING = 5, /* 1 (default): u8/i8 arrays by counting; 0: through the general pass */
+    RSX_OPT_MAX_REGIONS = 6,   /* 0 (default: 8 or 16 by element size) .. 32 look-back chains per pass */
+    RSX_OPT_HOT_LANES = 7,     /* 2..65 (default 16): lanes sharing a digit that mark a tile as skewed */
+    RSX_OPT_VERBOSE = 8        /* 1: launch geometry and self-test verdicts on stderr (also env RSX_VERBOSE=1) */
+};
+int rsx_ctx_set_option(rsx_ctx *ctx, int option, uint64_t value);
+enum {
+    RSX_INFO_RANK_ATOMIC = 1, /* 1 if the LDS atomic ordering self-test passed on this device */
+    RSX_INFO_L2_LOCAL = 2,    /* 1 if the same-XCD hand-off self-test passed on this device */
+    RSX_INFO_NUM_CU = 3,
+    RSX_INFO_DEVICE = 4
+};
+int rsx_ctx_get_info(rsx_ctx *ctx, int what, uint64_t *out);
 /* Per-launch timing with HIP events on the launch stream (measurement only).
  * rsx_ctx_profile(ctx, 1) clears the counters and makes every later kernel
  * launch of this context record a start/stop event pair around itself;
@@ -102,7 +137,8 @@ int rsx_sort_device(rsx_ctx *ctx, void *d_data, void *d_tmp, size_t n, const rsx
                     void *stream);
 
 /* Literal drop-in for `&mut [T]` in host memory: H2D, rsx_sort_device, D2H,
- * blocking (mod.rs:62 is blocking too).  PCIe-bound; not the measured path. */
+ * blocking (mod.rs:62 is blocking too).  The copies run as a pipeline over a ring of
+ * pinned chunks (the slice itself is pageable).  PCIe-bound; not the measured path. */
 int rsx_sort_host(rsx_ctx *ctx, void *data, size_t n, const rsx_layout *layout);
 
 /* -- per-pass building blocks (multi-GPU bucket exchange) ---------------- */
@@ -125,13 +161,6 @@ int rsx_segmented_copy_device(rsx_ctx *ctx, const void *d_src, void *d_dst, uint
                               const uint64_t *d_src_off, const uint64_t *d_dst_off,
                               const uint64_t *d_len, uint32_t nseg, void *stream);
 
-/* Order-preserving signed 64-bit form of every key (key_bytes <= 8): the mapped
- * key of radix_digits.rs zero-extended with its top bit flipped, so that signed
- * comparison of d_keys[i] equals the sort order.  The multi-GPU driver uses it to
- * find its splitters by binary search in locally sorted slices.  d_keys: n int64. */
-int rsx_extract_keys_device(rsx_ctx *ctx, const void *d_src, size_t n, const rsx_layout *layout,
-                            int64_t *d_keys, void *stream);
-
 /* Lower and upper bounds of `nq` 128-bit mapped-key queries in a slice that is
  * already sorted: d_queries holds nq pairs (low 64 bits, high 64 bits) of the
  * mapped key of radix_digits.rs:7-124 (unsigned order == sort order); d_out
@@ -150,25 +179,42 @@ int rsx_bounds_device(rsx_ctx *ctx, const void *d_sorted, size_t n, const rsx_la
  * of mod.rs:66-70,90-168 becomes "slice per GPU".  ctxs[g] is bound to the
  * device that holds d_slices[g] and d_tmps[g] (scratch of the same size as the
  * slice); one context per slice, several may share a device.  Blocking; uses
- * the NULL stream of every device; data crosses devices once (peer copies over
- * xGMI), between two local sorts.  Errors are reported on ctxs[0]. */
+ * one private stream per slice; data crosses devices once (peer copies over
+ * xGMI).  Errors are reported on ctxs[0]. */
 int rsx_sort_sharded(rsx_ctx *const *ctxs, uint32_t ndev, void *const *d_slices, void *const *d_tmps,
                      const size_t *n_per_dev, const rsx_layout *layout);
+/* The same with the schedule named.  Both move every element across devices once and give the
+ * same bytes:
+ *   RSX_SHARD_EXCHANGE_FIRST (what rsx_sort_sharded runs): one stable partition pass by the most
+ *     significant digit per slice, the G x 256 counts laid out globally (mod.rs:110-120 with chunk ==
+ *     slice), boundary buckets sorted locally and cut exactly, exchange, ONE local sort;
+ *   RSX_SHARD_SORT_FIRST: local sort, exact splitters by search in the sorted slices, exchange,
+ *     second local sort. */
+enum { RSX_SHARD_EXCHANGE_FIRST = 0, RSX_SHARD_SORT_FIRST = 1 };
+int rsx_sort_sharded_ex(rsx_ctx *const *ctxs, uint32_t ndev, void *const *d_slices, void *const *d_tmps,
+                        const size_t *n_per_dev, const rsx_layout *layout, int schedule);
 
 /* -- harness helpers (input generation / verification on device) --------- */
 enum {
     RSX_GEN_UNIFORM = 0, /* key = splitmix64(seed, i) truncated        (distr.rs:40-52 KeyUniform shape) */
-    RSX_GEN_ZIPF = 1,    /* key ~ Zipf(N = 2^bits - 1, s = param)      (distr.rs:54-76,108-130)         */
+    RSX_GEN_ZIPF = 1,    /* key ~ Zipf-shaped over [0, 2^bits - 1), exponent s = param: floor(2^(u bits)) - 1
+                            for s = 1                                   (distr.rs:54-76,108-130)         */
     RSX_GEN_STEP = 2,    /* key uniform over `param` equally spaced values (distr.rs:78-106,132-160)    */
     RSX_GEN_SORTED = 3,  /* key = i (already sorted)                                                   */
     RSX_GEN_REVERSED = 4,/* key = n-1-i                                                                */
-    RSX_GEN_CONSTANT = 5 /* key = param                                                                */
+    RSX_GEN_CONSTANT = 5,/* key = param                                                                */
+    RSX_GEN_GEOMETRIC = 6,/* key ~ Geometric(p = param): failures before the first success (distr.rs:3-38 MyExp) */
+    RSX_GEN_PAYLOAD_ZERO = 0x100 /* OR into `gen`: payload bytes are 0, the reference's `(key, 0)` pairs
+                                    (distr.rs:22-26,42-52), instead of the element's index */
 };
-/* Fills `n` elements: key field generated as above (counter-based, so the
- * same (seed, index) gives the same key on any device or on the host), every
- * payload byte outside the key holds the low bytes of the element's global
- * index `index_base + i` (reveals instability; the reference uses payload 0,
- * distr.rs:22-26). */
+/* Fills `n` elements: key field generated as above -- counter-based (splitmix64 of seed and
+ * index) and in integer arithmetic throughout, so the same (seed, index) gives the same key on
+ * any device and in the CPU restatement (tests/test_generators.py compares them byte for byte);
+ * the one exception is RSX_GEN_ZIPF with param != 1, which uses the device's double-precision
+ * pow.  The reference draws from rand_distr with an unseeded thread_rng: these are its
+ * distributions' shapes, not its streams.  Every payload byte outside the key holds the low
+ * bytes of the element's global index `index_base + i` (reveals instability) unless
+ * RSX_GEN_PAYLOAD_ZERO is set. */
 int rsx_generate_device(rsx_ctx *ctx, void *d_data, size_t n, const rsx_layout *layout, int gen,
                         uint64_t seed, double param, uint64_t index_base, void *stream);
 /* Order check + order-independent checksum, on device:

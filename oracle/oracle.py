@@ -61,6 +61,8 @@ def lib():
         L.orc_get_digit.restype = ctypes.c_uint32
         L.orc_rand64.argtypes = [ctypes.c_uint64, ctypes.c_uint64]
         L.orc_rand64.restype = ctypes.c_uint64
+        L.orc_generate.argtypes = [vp, sz, lp, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]
+        L.orc_generate.restype = ctypes.c_int
         _LIB = L
     return _LIB
 
@@ -104,6 +106,31 @@ def partition_pass(raw: np.ndarray, layout: Layout, digit: int):
     rc = lib().orc_partition_pass(raw.ctypes.data, out.ctypes.data, n, ctypes.byref(layout), digit, hist.ctypes.data)
     assert rc == 0
     return out, hist
+
+
+GEN_UNIFORM, GEN_ZIPF, GEN_STEP, GEN_SORTED, GEN_REVERSED, GEN_CONSTANT, GEN_GEOMETRIC = range(7)
+
+
+def generate(n: int, layout: Layout, gen: int, seed: int, param: float = 0.0, index_base: int = 0,
+             payload_zero: bool = False) -> np.ndarray:
+    """CPU restatement of rsx_generate_device: n elements as raw bytes.  `param` as the library takes it
+    (Zipf: exponent, must be 1; step: number of values; constant: the value; geometric: p)."""
+    import math
+    if gen == GEN_ZIPF:
+        assert param == 1.0, "only the exponent-1 Zipf shape is reproducible across host and device"
+        ip = 0
+    elif gen in (GEN_STEP, GEN_CONSTANT):
+        ip = int(param)
+    elif gen == GEN_GEOMETRIC:
+        c = -math.log2(1.0 - param) * 4294967296.0  # the library's expression (rsx.hip, rsx_generate_device)
+        ip = 1 if c < 1.0 else (2 ** 64 - 1 if c >= 18446744073709551615.0 else int(c))
+    else:
+        ip = 0
+    out = np.zeros(n * layout.elem_bytes, dtype=np.uint8)
+    rc = lib().orc_generate(out.ctypes.data, n, ctypes.byref(layout), gen, seed & (2 ** 64 - 1), ip, index_base,
+                            1 if payload_zero else 0)
+    assert rc == 0
+    return out
 
 
 def map_keys(raw: np.ndarray, layout: Layout) -> np.ndarray:

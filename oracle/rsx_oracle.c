@@ -282,3 +282,99 @@ static inline uint64_t orc_splitmix64(uint64_t x) {
     return x ^ (x >> 31);
 }
 uint64_t orc_rand64(uint64_t seed, uint64_t index) { return orc_splitmix64(seed + index * 0x9E3779B97F4A7C15ull); }
+
+/* ---- input generators ---------------------------------------------------------
+ * CPU restatement of the library's on-device generators (rsx_generate_device), which in turn
+ * give the SHAPES of the reference's distributions (src/distr.rs: KeyUniform :40-52, Zipf
+ * :54-76,108-130, step-uniform :78-106,132-160, geometric MyExp :3-38, `(key, 0)` pairs
+ * :22-26) -- the reference draws from rand_distr with an unseeded thread_rng, so there is no
+ * stream of its own to reproduce.  Integer arithmetic only: the same (seed, index) must give the
+ * same bytes here and on the device (tests/test_generators.py).
+ *   2^(2^-i) as 1.63 fixed point, i = 1..32 */
+static const uint64_t ORC_EXP2_TAB[32] = {
+    0xB504F333F9DE6484ull, 0x9837F0518DB8A96Full, 0x8B95C1E3EA8BD6E7ull, 0x85AAC367CC487B15ull,
+    0x82CD8698AC2BA1D7ull, 0x8164D1F3BC030773ull, 0x80B1ED4FD999AB6Cull, 0x8058D7D2D5E5F6B1ull,
+    0x802C6436D0E04F51ull, 0x8016302F17467628ull, 0x800B179C82028FD1ull, 0x80058BAF7FEE3B5Dull,
+    0x8002C5D00FDCFCB7ull, 0x800162E61BED4A49ull, 0x8000B17292F702A4ull, 0x800058B92ABBAE02ull,
+    0x80002C5C8DADE4D7ull, 0x8000162E44EAF636ull, 0x80000B1721FA7C19ull, 0x8000058B90DE7E4Dull,
+    0x800002C5C8678F37ull, 0x80000162E431DBA0ull, 0x800000B1721872D1ull, 0x80000058B90C1AA9ull,
+    0x8000002C5C8605A4ull, 0x800000162E4300E6ull, 0x8000000B17217FF8ull, 0x800000058B90BFDDull,
+    0x80000002C5C85FE7ull, 0x8000000162E42FF2ull, 0x80000000B17217F8ull, 0x8000000058B90BFCull};
+
+static inline uint64_t orc_mulhi64(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
+
+/* floor(2^(e + f/2^32)), 0 <= e <= 63 */
+static uint64_t orc_exp2_floor(uint32_t e, uint32_t f) {
+    uint64_t m = 1ull << 63;
+    for (int i = 0; i < 32; ++i)
+        if (f & (0x80000000u >> i)) m = orc_mulhi64(m, ORC_EXP2_TAB[i]) << 1;
+    return m >> (63u - e);
+}
+/* -log2(w / 2^64), w >= 1, as 32.32 fixed point */
+static uint64_t orc_neg_log2(uint64_t w) {
+    const uint32_t lz = (uint32_t)__builtin_clzll(w);
+    uint64_t m = w << lz;
+    uint32_t frac = 0;
+    for (int i = 0; i < 32; ++i) {
+        m = orc_mulhi64(m, m);
+        if (m >> 63) frac |= 0x80000000u >> i;
+        else m <<= 1;
+    }
+    return (64ull << 32) - ((((uint64_t)(63u - lz)) << 32) | frac);
+}
+
+enum { ORC_GEN_UNIFORM = 0, ORC_GEN_ZIPF = 1, ORC_GEN_STEP = 2, ORC_GEN_SORTED = 3, ORC_GEN_REVERSED = 4,
+       ORC_GEN_CONSTANT = 5, ORC_GEN_GEOMETRIC = 6 };
+
+/* iparam: STEP: number of values; CONSTANT: the value; GEOMETRIC: -log2(1 - p) as 32.32 fixed point
+ * (the caller makes it from p with the same expression the library uses).  ZIPF: exponent 1 only. */
+int orc_generate(void *data, size_t n, const orc_layout *L, int gen, uint64_t seed, uint64_t iparam,
+                 uint64_t index_base, int payload_zero) {
+    uint8_t *p = (uint8_t *)data;
+    const uint32_t bits = L->key_bytes * 8;
+    if (gen < ORC_GEN_UNIFORM || gen > ORC_GEN_GEOMETRIC) return -1;
+    if ((gen == ORC_GEN_STEP || gen == ORC_GEN_GEOMETRIC) && iparam == 0) return -1;
+    for (size_t i = 0; i < n; ++i) {
+        const uint64_t gi = index_base + i;
+        uint64_t lo = 0, hi = 0;
+        switch (gen) {
+        case ORC_GEN_UNIFORM:
+            lo = orc_rand64(seed, gi);
+            hi = orc_rand64(seed ^ 0xA5A5A5A5A5A5A5A5ull, gi);
+            break;
+        case ORC_GEN_ZIPF: { /* x = floor(2^(u * bits)) - 1: the continuous inverse of H(x) = ln x */
+            const uint64_t r = orc_rand64(seed, gi);
+            const uint64_t t = (r >> 32) * (uint64_t)(bits >= 64 ? 64u : bits);
+            lo = orc_exp2_floor((uint32_t)(t >> 32), (uint32_t)t) - 1;
+            break;
+        }
+        case ORC_GEN_STEP: { /* distr.rs:85-93: s = MAX / (n + 1); values s, 2s, .., n s */
+            const uint64_t maxv = bits >= 64 ? ~0ull : ((1ull << bits) - 1);
+            const uint64_t s = maxv / (iparam + 1);
+            lo = s * (1 + orc_rand64(seed, gi) % iparam);
+            break;
+        }
+        case ORC_GEN_SORTED: lo = gi; break;
+        case ORC_GEN_REVERSED: lo = index_base + n - 1 - gi; break;
+        case ORC_GEN_GEOMETRIC: { /* failures before the first success, by inversion: floor(log2 U / log2(1 - p)) */
+            uint64_t w = orc_rand64(seed, gi);
+            if (w == 0) w = 1;
+            lo = orc_neg_log2(w) / iparam;
+            break;
+        }
+        default: lo = iparam; break;
+        }
+        uint8_t *e = p + i * L->elem_bytes;
+        uint32_t pb = 0;
+        for (uint32_t b = 0; b < L->elem_bytes; ++b) {
+            if (b >= L->key_offset && b < L->key_offset + L->key_bytes) {
+                const uint32_t kb = b - L->key_offset;
+                e[b] = (uint8_t)((kb < 8 ? lo >> (8 * kb) : hi >> (8 * (kb - 8))) & 0xFF);
+            } else {
+                e[b] = (pb < 8 && !payload_zero) ? (uint8_t)((gi >> (8 * pb)) & 0xFF) : 0;
+                ++pb;
+            }
+        }
+    }
+    return 0;
+}

@@ -134,7 +134,18 @@ class Context:
         self._check(self._L.rsx_ctx_reserve(self._h, n, ctypes.byref(lay)))
 
     def check(self, stream: int = 0):
+        """rsx_ctx_check: synchronises `stream` and raises if a kernel of this context gave up a
+        device-side wait (the stream-ordered entry points cannot report that by themselves)."""
         self._check(self._L.rsx_ctx_check(self._h, stream))
+
+    def set_option(self, option: int, value: int):
+        """rsx_ctx_set_option (OPT_* in _lib): forces one of the bit-exact alternative kernel paths."""
+        self._check(self._L.rsx_ctx_set_option(self._h, option, value))
+
+    def get_info(self, what: int) -> int:
+        out = ctypes.c_uint64(0)
+        self._check(self._L.rsx_ctx_get_info(self._h, what, ctypes.byref(out)))
+        return int(out.value)
 
     def profile(self, enable: bool):
         """Per-launch HIP-event timing on/off (rsx_ctx_profile); enabling clears the counters."""
@@ -173,10 +184,6 @@ class Context:
     def bounds_device(self, d_sorted: int, n: int, d: RadixDigits, d_queries: int, nq: int, d_out: int, stream: int = 0):
         lay = d.layout()
         self._check(self._L.rsx_bounds_device(self._h, d_sorted, n, ctypes.byref(lay), d_queries, nq, d_out, stream))
-
-    def extract_keys_device(self, d_src: int, n: int, d: RadixDigits, d_keys: int, stream: int = 0):
-        lay = d.layout()
-        self._check(self._L.rsx_extract_keys_device(self._h, d_src, n, ctypes.byref(lay), d_keys, stream))
 
     def generate_device(self, d_data: int, n: int, d: RadixDigits, gen: int, seed: int, param: float = 0.0,
                         index_base: int = 0, stream: int = 0):
@@ -264,11 +271,13 @@ def radix_sort(x, digits: Optional[RadixDigits] = None, tmp=None, ctx: Optional[
     return None
 
 
-def radix_sort_sharded(slices: Sequence, digits: RadixDigits, ctxs: Optional[Sequence[Context]] = None, tmps=None):
+def radix_sort_sharded(slices: Sequence, digits: RadixDigits, ctxs: Optional[Sequence[Context]] = None, tmps=None,
+                       schedule: int = _lib.SHARD_EXCHANGE_FIRST):
     """rsx_sort_sharded: sorts the concatenation of `slices` (contiguous GPU tensors, one per
     context, possibly on different devices) as ONE array, stably and in place -- every slice
     keeps its length.  The single-process multi-GPU form of `<[T]>::radix_sort` with "chunk per
-    thread" (mod.rs:66-70) read as "slice per GPU".  Blocking."""
+    thread" (mod.rs:66-70) read as "slice per GPU".  Blocking.  `schedule`: SHARD_EXCHANGE_FIRST (one
+    partition pass by the top digit, exchange, one local sort) or SHARD_SORT_FIRST (sort, exchange, sort)."""
     import torch
     G = len(slices)
     if G == 0:
@@ -287,7 +296,7 @@ def radix_sort_sharded(slices: Sequence, digits: RadixDigits, ctxs: Optional[Seq
         if nbytes % digits.elem_bytes or u.numel() * u.element_size() < nbytes:
             raise ValueError("slice size is not a multiple of elem_bytes, or tmp too small")
         ns.append(nbytes // digits.elem_bytes)
-    for t in slices:  # the library works on the NULL stream of each device
+    for t in slices:  # the library works on private streams: what torch enqueued must be done
         torch.cuda.synchronize(t.device)
     L = ctxs[0]._L
     hs = (ctypes.c_void_p * G)(*[c._h for c in ctxs])
@@ -295,5 +304,5 @@ def radix_sort_sharded(slices: Sequence, digits: RadixDigits, ctxs: Optional[Seq
     ts = (ctypes.c_void_p * G)(*[t.data_ptr() for t in tmps])
     nn = (ctypes.c_size_t * G)(*ns)
     lay = digits.layout()
-    ctxs[0]._check(L.rsx_sort_sharded(hs, G, ps, ts, nn, ctypes.byref(lay)))
+    ctxs[0]._check(L.rsx_sort_sharded_ex(hs, G, ps, ts, nn, ctypes.byref(lay), schedule))
     return None

@@ -2,101 +2,16 @@
 // kernels in rsx_device.hpp.  Plays the role of the body of
 // `<[T]>::radix_sort` (reference src/radix_sort/mod.rs:62-175): pass loop,
 // ping-pong, odd-D copy-back -- with every phase a stream-ordered launch.
-#include "rsx_device.hpp"
+// The per-element-size kernel launchers live in rsx_es.hip (one object per size).
+#include "rsx_internal.hpp"
+#include "rsx_misc_kernels.hpp"
 
-#include <hip/hip_runtime.h>
-
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <mutex>
-#include <new>
-#include <string>
-#include <utility>
-#include <vector>
-
-#include "../../include/rsx.h"
+#include <cmath>
 
 using namespace rsx;
+using namespace rsxh;
 
 namespace {
-// aux block layout (one hipMalloc, zeroed at creation)
-constexpr size_t J_BYTES = (size_t)MAX_REGIONS * RADIX * sizeof(uint64_t);  // one count matrix
-constexpr size_t OFF_J0 = 0;
-constexpr size_t OFF_J1 = OFF_J0 + J_BYTES;
-constexpr size_t OFF_BASE = OFF_J1 + J_BYTES;       // [MAX_REGIONS][256] write cursors
-constexpr size_t OFF_TICKETS = OFF_BASE + J_BYTES;  // [MAX_REGIONS] u32
-constexpr size_t OFF_ERROR = OFF_TICKETS + 192;  // tickets[MAX_REGIONS] + roll-call words
-constexpr size_t OFF_DBG = OFF_ERROR + 64;  // 8 diagnostic counters
-constexpr size_t AUX_BYTES = OFF_DBG + 1024;  // 16 waves x 8 diagnostic counters
-}  // namespace
-
-struct rsx_ctx {
-    int device = 0;
-    std::mutex mu;
-    std::string err = "";
-    void* status = nullptr;  // tile status words, zeroed before every pass
-    size_t status_bytes = 0;
-    char* aux = nullptr;
-    // staging for rsx_sort_host
-    void* host_buf[2] = {nullptr, nullptr};
-    size_t host_bytes = 0;
-    int num_cu = 256;
-    uint32_t pass_index = 0;   // of the sweep being launched within its sort (selects the status half)
-    bool pass_last = true;     // no pass follows: nothing to clean
-    bool rank_atomic = false;  // LDS atomic ordering self-test passed (set when the workspace is first made)
-    uint32_t hot_lanes = 16;   // RSX_HOT env (tuning)
-    uint32_t dbg = 0;  // RSX_DEBUG env: timing-only ablation switches for the sweep kernel
-    // per-launch HIP-event timing (rsx_ctx_profile)
-    bool prof = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending[RSX_PROF_KINDS];
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_free;
-    double prof_ms[RSX_PROF_KINDS] = {0, 0, 0, 0};
-    uint64_t prof_n[RSX_PROF_KINDS] = {0, 0, 0, 0};
-};
-
-namespace {
-
-int fail(rsx_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
-    if (c) {
-        c->err = what;
-        if (e != hipSuccess) {
-            c->err += ": ";
-            c->err += hipGetErrorString(e);
-        }
-    }
-    return code;
-}
-
-#define RSX_HIP(call)                                                   \
-    do {                                                                \
-        hipError_t _e = (call);                                         \
-        if (_e != hipSuccess) return fail(ctx, RSX_ERR_HIP, #call, _e); \
-    } while (0)
-
-// Records a start/stop event pair around one launch when profiling is on.
-struct LaunchTimer {
-    rsx_ctx* c;
-    int kind;
-    hipStream_t st;
-    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
-    LaunchTimer(rsx_ctx* ctx, int k, hipStream_t s) : c(ctx), kind(k), st(s) {
-        if (!c->prof) return;
-        if (!c->prof_free.empty()) {
-            ev = c->prof_free.back();
-            c->prof_free.pop_back();
-        } else if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) {
-            ev = {nullptr, nullptr};
-            return;
-        }
-        (void)hipEventRecord(ev.first, st);
-    }
-    ~LaunchTimer() {
-        if (!ev.first) return;
-        (void)hipEventRecord(ev.second, st);
-        c->prof_pending[kind].push_back(ev);
-    }
-};
 
 bool layout_ok(const rsx_layout* L) {
     if (!L) return false;
@@ -121,117 +36,75 @@ uint32_t elem_align(uint32_t es) {
 }
 bool aligned(const void* p, uint32_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
-// Keys per thread by element size.  Tiles need not be powers of two (the last tile of a region is
-// partial anyway); bigger tiles mean longer output runs per digit (fewer partial cache lines, the
-// memory system's real cost here) and fewer look-backs per key, as long as two or three workgroups
-// still fit a CU: u32 28 x 512 = 14336 keys (56 KiB), u64 12 x 512 (48 KiB), 16-byte 5 x 512 (40 KiB),
-// 12-byte 10 x 512 (60 KiB), 24/32-byte 3 x 512 (36/48 KiB).
-// Measured against 16 / 8 / 4: 1B u32 117 -> 136, 1B u64 32 -> 34.9, 128M (u64,u64) 17.3 -> 18 Gkeys/s.
-#ifndef RSX_KPT4
-#define RSX_KPT4 28
-#endif
-#ifndef RSX_WG4
-#define RSX_WG4 512
-#endif
-#ifndef RSX_KPT8
-#define RSX_KPT8 12
-#endif
-#ifndef RSX_KPT16
-#define RSX_KPT16 5
-#endif
-#ifndef RSX_KPT12
-#define RSX_KPT12 10
-#endif
-#ifndef RSX_KPT32
-#define RSX_KPT32 3
-#endif
-#ifndef RSX_WG8
-#define RSX_WG8 512
-#endif
-constexpr int kpt_for(int es) { return es <= 4 ? RSX_KPT4 : es == 8 ? RSX_KPT8 : es == 12 ? RSX_KPT12 : es == 16 ? RSX_KPT16 : RSX_KPT32; }
-constexpr int wg_for(int es) { return es <= 4 ? RSX_WG4 : es == 8 ? RSX_WG8 : 512; }
-constexpr uint32_t tile_elems(int es) { return wg_for(es) * kpt_for(es); }
-
-uint32_t log2u(uint64_t x) { return 63u - (uint32_t)__builtin_clzll(x); }
-
-// Regions: smallest power-of-two length (>= one tile) that covers n with <= MAX_REGIONS of them.
-RegionGeom make_geom(uint64_t n, uint32_t es) {
-    RegionGeom g;
-    g.n = n;
-    uint32_t k = log2u(tile_elems((int)es));
-    if ((1ull << k) < tile_elems((int)es)) ++k;  // tiles need not be a power of two; regions are
-    static const uint64_t max_regions = [] {  // RSX_REGIONS env: tuning/diagnostics only
-        const char* e = std::getenv("RSX_REGIONS");
-        const uint64_t v = e ? std::strtoull(e, nullptr, 0) : 0;
-        return (v >= 1 && v <= (uint64_t)MAX_REGIONS) ? v : 0;
-    }();
-    // the next pass's count matrix costs 1 KiB of LDS per region: 8 where the tile needs the room
-    const uint64_t cap = max_regions ? max_regions : (es == 8 || es > 16) ? 16 : 8;
-    while (((n + (1ull << k) - 1) >> k) > cap) ++k;
-    g.region_shift = k;
-    g.num_regions = (uint32_t)((n + (1ull << k) - 1) >> k);
-    if (g.num_regions == 0) g.num_regions = 1;
-    return g;
+bool capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
 }
-uint64_t tiles_per_region(const RegionGeom& g, uint32_t es) {
-    const uint64_t t = tile_elems((int)es);
-    return ((1ull << g.region_shift) + t - 1) / t;
-}
-uint64_t status_rows(const RegionGeom& g, uint32_t es) {
-    return (uint64_t)g.num_regions * tiles_per_region(g, es);
-}
-// chain prefixes are relative to the region: 30 value bits suffice up to 2^30-element regions
-bool status32(const RegionGeom& g) { return g.region_shift <= 30; }
 
-DigitSpec make_spec(const rsx_layout* L, uint32_t digit) {
-    DigitSpec s;
-    const uint32_t byte = L->key_offset + digit;
-    const uint32_t top = L->key_offset + L->key_bytes - 1;
-    if (L->elem_bytes >= 4) {
-        s.word = byte >> 2;
-        s.shift = 8 * (byte & 3);
-        s.top_word = top >> 2;
-        s.top_shift = 8 * (top & 3) + 7;
-    } else {  // 1- and 2-byte elements live in one register
-        s.word = 0;
-        s.shift = 8 * byte;
-        s.top_word = 0;
-        s.top_shift = 8 * top + 7;
+// Brackets the work ONE API call enqueues on `st`: the context's device workspace (count matrices,
+// tickets, status words) belongs to one sort at a time, so work arriving on a different stream than
+// the context's last enqueue first waits for that enqueue (an event, no host sync).  Inside a stream
+// capture nothing is recorded: ordering between replays is the graph owner's business.
+struct Enqueue {
+    rsx_ctx* c;
+    hipStream_t st;
+    bool live;
+    Enqueue(rsx_ctx* ctx, hipStream_t s) : c(ctx), st(s), live(ctx->last_event != nullptr && !capturing(s)) {
+        if (live && c->busy && c->last_stream != st) (void)hipStreamWaitEvent(st, c->last_event, 0);
     }
-    s.flip = (L->key_kind != RSX_KEY_UNSIGNED && digit == L->key_bytes - 1) ? 0x80u : 0u;
-    s.fsign = L->key_kind == RSX_KEY_FLOAT ? ~0u : 0u;
-    return s;
-}
+    ~Enqueue() {
+        if (!live) return;
+        (void)hipEventRecord(c->last_event, st);
+        c->busy = true;
+        c->last_stream = st;
+    }
+};
 
-unsigned long long* J_of(rsx_ctx* c, int which) {
-    return reinterpret_cast<unsigned long long*>(c->aux + (which ? OFF_J1 : OFF_J0));
-}
-uint64_t* base_of(rsx_ctx* c) { return reinterpret_cast<uint64_t*>(c->aux + OFF_BASE); }
-uint32_t* tickets_of(rsx_ctx* c) { return reinterpret_cast<uint32_t*>(c->aux + OFF_TICKETS); }
-uint32_t* error_of(rsx_ctx* c) { return reinterpret_cast<uint32_t*>(c->aux + OFF_ERROR); }
-
-size_t status_bytes_for(size_t n, uint32_t es) {
-    const RegionGeom g = make_geom(n, es);
+size_t status_bytes_for(const rsx_ctx* ctx, size_t n, uint32_t es) {
+    const RegionGeom g = make_geom(ctx, n, es);
     return (size_t)status_rows(g, es) * RADIX * (status32(g) ? 4 : 8);
 }
 
-int ensure_workspace(rsx_ctx* ctx, size_t n, const rsx_layout* L) {
-    if (!ctx->aux) {
-        void* p = nullptr;
-        RSX_HIP(hipMalloc(&p, AUX_BYTES));
-        ctx->aux = static_cast<char*>(p);
-        RSX_HIP(hipMemset(ctx->aux, 0, AUX_BYTES));
-        // may the sweep rank by returned LDS atomics on this device?  (see rsx_lds_order_kernel)
-        uint32_t* flag = error_of(ctx) + 1;
-        hipLaunchKernelGGL(rsx_lds_order_kernel, dim3(64), dim3(512), 0, nullptr, flag);
-        RSX_HIP(hipGetLastError());
-        uint32_t failed = 1;
-        RSX_HIP(hipMemcpy(&failed, flag, sizeof failed, hipMemcpyDeviceToHost));
-        ctx->rank_atomic = failed == 0 && !(ctx->dbg & 0x10000u);
-        if (ctx->dbg & 0x200u) std::fprintf(stderr, "[rsx] LDS atomic order self-test %s\n", failed ? "FAILED: ballots only" : "passed");
+// First use of a context on its device: aux block, host-visible error word, the two device self-tests.
+int ensure_aux(rsx_ctx* ctx, hipStream_t st) {
+    if (ctx->aux) return RSX_OK;
+    if (capturing(st)) return fail(ctx, RSX_ERR_WORKSPACE, "workspace not reserved (rsx_ctx_reserve) before stream capture");
+    void* p = nullptr;
+    RSX_HIP(hipMalloc(&p, AUX_BYTES));
+    ctx->aux = static_cast<char*>(p);
+    RSX_HIP(hipMemset(ctx->aux, 0, AUX_BYTES));
+    RSX_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->host_err), 64, hipHostMallocMapped));
+    std::memset(ctx->host_err, 0, 64);
+    RSX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->host_err_dev), ctx->host_err, 0));
+    RSX_HIP(hipEventCreateWithFlags(&ctx->last_event, hipEventDisableTiming));
+    uint32_t* flags = flags_of(ctx);  // [0] LDS order failures, [4..6] L2 probe {pairs, cross-CU pairs, failures}, [16..] probe words
+    // may the sweep rank by returned LDS atomics on this device?  (see rsx_lds_order_kernel)
+    hipLaunchKernelGGL(rsx_lds_order_kernel, dim3(64), dim3(512), 0, nullptr, flags);
+    RSX_HIP(hipGetLastError());
+    // may a single-XCD chain keep its status words in that XCD's L2?  (see rsx_l2_probe_kernel)
+    uint32_t* probe_words = reinterpret_cast<uint32_t*>(ctx->aux + OFF_BASE);  // scratch: 32 pairs x 4 words (zeroed above)
+    hipLaunchKernelGGL(rsx_l2_probe_kernel, dim3(64), dim3(64), 0, nullptr, probe_words, flags + 4, 64u);
+    RSX_HIP(hipGetLastError());
+    uint32_t v[8] = {1, 0, 0, 0, 0, 0, 1, 0};
+    RSX_HIP(hipMemcpy(v, flags, sizeof v, hipMemcpyDeviceToHost));
+    RSX_HIP(hipMemset(ctx->aux + OFF_BASE, 0, 32 * 4 * sizeof(uint32_t)));
+    ctx->rank_atomic = v[0] == 0;
+    ctx->l2_local = v[4] > 0 && v[5] > 0 && v[6] == 0;  // some same-XCD pair on two CUs ran, none missed a value
+    if (ctx->options & OPT_VERBOSE) {
+        std::fprintf(stderr, "[rsx] LDS atomic order self-test %s\n", v[0] ? "FAILED: ballots only" : "passed");
+        std::fprintf(stderr, "[rsx] same-XCD hand-off self-test: %u pairs on one XCD, %u of them on two CUs, %u failures -> %s\n",
+                     v[4], v[5], v[6], ctx->l2_local ? "passed" : "agent-scope status stores");
     }
-    const size_t need = status_bytes_for(n, L->elem_bytes);
+    return RSX_OK;
+}
+
+int ensure_workspace(rsx_ctx* ctx, size_t n, const rsx_layout* L, hipStream_t st) {
+    int rc = ensure_aux(ctx, st);
+    if (rc) return rc;
+    const size_t need = status_bytes_for(ctx, n, L->elem_bytes);
     if (need > ctx->status_bytes) {
+        if (capturing(st)) return fail(ctx, RSX_ERR_WORKSPACE, "workspace too small for this sort and a stream capture is active (rsx_ctx_reserve first)");
+        if (ctx->busy) RSX_HIP(hipEventSynchronize(ctx->last_event));  // the old block may still be in use
         if (ctx->status) RSX_HIP(hipFree(ctx->status));
         ctx->status = nullptr;
         ctx->status_bytes = 0;
@@ -240,170 +113,6 @@ int ensure_workspace(rsx_ctx* ctx, size_t n, const rsx_layout* L) {
         ctx->status_bytes = need;
     }
     return RSX_OK;
-}
-
-// ---- count phase of a first pass: J[r][v] for `digit` over the input regions ------------------
-template <int ES, bool FLT>
-int launch_hist_t(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_layout* L, uint32_t digit,
-                  unsigned long long* J, hipStream_t st) {
-    RSX_HIP(hipMemsetAsync(J, 0, J_BYTES, st));
-    const uint64_t per_block = 512ull * 16;
-    uint64_t bpr = ((1ull << g.region_shift) + per_block - 1) / per_block;
-    const uint64_t cap = ((uint64_t)ctx->num_cu * 8 + g.num_regions - 1) / g.num_regions;
-    if (bpr > cap) bpr = cap;
-    if (bpr == 0) bpr = 1;
-    LaunchTimer lt(ctx, RSX_PROF_HIST, st);
-    hipLaunchKernelGGL((rsx_hist_kernel<ES, FLT>), dim3((uint32_t)(bpr * g.num_regions)), dim3(512), 0, st,
-                       static_cast<const Elem<ES>*>(src), g, make_spec(L, digit), (uint32_t)bpr, J);
-    RSX_HIP(hipGetLastError());
-    return RSX_OK;
-}
-template <int ES>
-int launch_hist(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_layout* L, uint32_t digit,
-                unsigned long long* J, hipStream_t st) {
-    if (L->key_kind == RSX_KEY_FLOAT || (L->key_kind == RSX_KEY_SIGNED && digit + 1 == L->key_bytes))
-        return launch_hist_t<ES, true>(ctx, src, g, L, digit, J, st);
-    return launch_hist_t<ES, false>(ctx, src, g, L, digit, J, st);
-}
-
-// ---- prefix phase ------------------------------------------------------------------------------
-int launch_prefix(rsx_ctx* ctx, const RegionGeom& g, const unsigned long long* J, unsigned long long* jnext,
-                  uint64_t* counts_out, hipStream_t st) {
-    LaunchTimer lt(ctx, RSX_PROF_SCAN, st);
-    hipLaunchKernelGGL(rsx_prefix_kernel, dim3(1), dim3(RADIX), 0, st, J, g.num_regions, base_of(ctx), jnext,
-                       tickets_of(ctx), counts_out);
-    RSX_HIP(hipGetLastError());
-    return RSX_OK;
-}
-
-// ---- scatter phase: one sweep pass -------------------------------------------------------------
-// the per-dword masks of the signed/float key map (KeyXform in rsx_device.hpp)
-KeyXform make_xform(const rsx_layout* L) {
-    KeyXform x;
-    std::memset(&x, 0, sizeof x);
-    if (L->key_kind == RSX_KEY_UNSIGNED) return x;
-    const uint32_t top = L->key_offset + L->key_bytes - 1;
-    auto word_of = [&](uint32_t byte) { return L->elem_bytes >= 4 ? byte >> 2 : 0u; };
-    auto bit_of = [&](uint32_t byte) { return L->elem_bytes >= 4 ? 8 * (byte & 3) : 8 * byte; };
-    const uint32_t sw = word_of(top);
-    const uint32_t sbit = 1u << (bit_of(top) + 7);
-    x.sign[sw] = sbit;
-    x.xpos[sw] = sbit;
-    if (L->key_kind == RSX_KEY_SIGNED) {
-        x.xneg[sw] = sbit;
-    } else {
-        for (uint32_t b = L->key_offset; b <= top; ++b) x.xneg[word_of(b)] |= 0xFFu << bit_of(b);
-    }
-    return x;
-}
-
-template <int ES, typename S, int XF, bool NEXT>
-int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L,
-                   uint32_t digit, unsigned long long* jnext, hipStream_t st) {
-    constexpr int KPT = kpt_for(ES);
-    constexpr int SWEEP_WG = wg_for(ES);
-    constexpr int TILE = SWEEP_WG * KPT;
-    const uint64_t rows = status_rows(g, ES);
-    // Status words alternate between the two halves of the workspace.  Only the first pass of a
-    // sort zeroes its half with a memset; every pass zeroes, tile by tile, the half of the next.
-    char* const half[2] = {static_cast<char*>(ctx->status), static_cast<char*>(ctx->status) + ctx->status_bytes};
-    const uint32_t which = ctx->pass_index & 1u;
-    if (ctx->pass_index == 0) RSX_HIP(hipMemsetAsync(half[0], 0, (size_t)rows * RADIX * sizeof(S), st));
-    SweepArgs a;
-    a.status_clean = ctx->pass_last ? nullptr : half[which ^ 1u];
-    a.src = src;
-    a.dst = dst;
-    a.g = g;
-    a.region_base = base_of(ctx);
-    a.status = half[which];
-    a.tickets = tickets_of(ctx);
-    a.jnext = jnext;
-    a.error = error_of(ctx);
-    a.spec = make_spec(L, digit);
-    a.next = make_spec(L, NEXT ? digit + 1 : digit);
-    a.spec.flip = a.next.flip = 0;  // the sweep sees mapped keys: plain digits
-    a.xf = make_xform(L);
-    a.tiles_per_region = (uint32_t)tiles_per_region(g, ES);
-    a.dbg = ctx->dbg;
-    a.rank_atomic = ctx->rank_atomic ? 1u : 0u;
-    a.hot_lanes = (ctx->dbg & 0x20000u) ? 65u : ctx->hot_lanes;  // 0x20000: atomics whatever the skew (timing only)
-    a.dbg_cnt = reinterpret_cast<unsigned long long*>(ctx->aux + OFF_DBG);
-    const size_t lds = (size_t)TILE * ES + (SWEEP_WG / WAVE) * RADIX * ((RSX_WIDE_CNT && ES <= 4 && KPT >= 16 && SWEEP_WG <= 512) ? sizeof(uint32_t) : sizeof(uint16_t)) +
-                       (NEXT ? (size_t)g.num_regions * RADIX * sizeof(uint32_t) : 0) + 64;
-    auto kern = rsx_sweep_kernel<ES, KPT, SWEEP_WG, S, XF, NEXT>;
-    // resident workgroups per CU for this kernel at this LDS size (the count matrix of the next pass
-    // makes the LDS size depend on the number of regions): cached per instantiation and thread
-    thread_local size_t occ_lds = ~(size_t)0;
-    thread_local int occ = 0;
-    if (occ == 0 || occ_lds != lds) {
-        int o = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kern, SWEEP_WG, lds) != hipSuccess || o < 1) o = 2;
-        occ = o;
-        occ_lds = lds;
-    }
-    // persistent workgroups; correctness does not need them co-resident (a workgroup only
-    // ever waits for tiles whose tickets were drawn earlier, by workgroups already running)
-    const uint64_t total_tiles = (g.n + TILE - 1) / TILE + g.num_regions;
-    uint64_t grid = (uint64_t)ctx->num_cu * occ;
-    if (grid > total_tiles) grid = total_tiles;
-    if (const char* o = std::getenv("RSX_OCC")) grid = (uint64_t)ctx->num_cu * std::atoi(o);  // tuning only
-    {   // static mode: workgroups per region, proportional to the region's tile count, >= 1 each
-        const uint32_t NR = g.num_regions;
-        const uint64_t tpr = tiles_per_region(g, ES);
-        const uint64_t real_tiles = (g.n + TILE - 1) / TILE;
-        uint64_t cum = 0;
-        for (uint32_t r = 0; r < NR; ++r) {
-            a.wg_first[r] = (uint16_t)(cum * grid / real_tiles);
-            const uint64_t left = real_tiles - cum;
-            cum += left < tpr ? left : tpr;
-        }
-        a.wg_first[NR] = (uint16_t)grid;
-        for (uint32_t r = 0; r < NR; ++r)  // at least one workgroup per region
-            if (a.wg_first[r + 1] <= a.wg_first[r]) a.wg_first[r + 1] = a.wg_first[r] + 1;
-        for (uint32_t r = NR; r-- > 0;) {
-            const uint32_t cap = (uint32_t)grid - (NR - r);
-            if (a.wg_first[r] > cap) a.wg_first[r] = (uint16_t)cap;
-        }
-        a.wg_first[NR] = (uint16_t)grid;
-        for (uint32_t r = NR + 1; r <= (uint32_t)MAX_REGIONS; ++r) a.wg_first[r] = (uint16_t)grid;
-        // regions whose workgroups fall into one class of the kernel's XCD-major numbering
-        // (class = index / (grid/8) = blockIdx % 8): candidates for L2-local status words
-        a.local_mask = 0;
-        if (grid % 8 == 0 && !(ctx->dbg & 0x4000u))
-            for (uint32_t r = 0; r < NR; ++r)
-                if (a.wg_first[r] / (grid / 8) == (a.wg_first[r + 1] - 1u) / (grid / 8)) a.local_mask |= 1u << r;
-    }
-    if (ctx->dbg & 0x200u) std::fprintf(stderr, "[rsx] sweep ES=%d NEXT=%d occ=%d grid=%llu lds=%zu tiles=%llu regions=%u\n", ES, (int)NEXT, occ, (unsigned long long)grid, lds, (unsigned long long)total_tiles, g.num_regions);
-    LaunchTimer lt(ctx, RSX_PROF_SWEEP, st);
-    hipLaunchKernelGGL(kern, dim3((uint32_t)grid), dim3(SWEEP_WG), lds, st, a);
-    RSX_HIP(hipGetLastError());
-    return RSX_OK;
-}
-
-template <int ES, typename S, int XF>
-int launch_sweep_n(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L,
-                   uint32_t digit, unsigned long long* jnext, hipStream_t st) {
-    if (jnext) return launch_sweep_t<ES, S, XF, true>(ctx, src, dst, g, L, digit, jnext, st);
-    return launch_sweep_t<ES, S, XF, false>(ctx, src, dst, g, L, digit, jnext, st);
-}
-
-// xf: bit 0 = map signed/float keys on load (first pass), bit 1 = map back on store (last pass)
-template <int ES, typename S>
-int launch_sweep_x(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L,
-                   uint32_t digit, unsigned long long* jnext, int xf, hipStream_t st) {
-    switch (L->key_kind == RSX_KEY_UNSIGNED ? 0 : xf) {
-        case 1: return launch_sweep_n<ES, S, 1>(ctx, src, dst, g, L, digit, jnext, st);
-        case 2: return launch_sweep_n<ES, S, 2>(ctx, src, dst, g, L, digit, jnext, st);
-        case 3: return launch_sweep_n<ES, S, 3>(ctx, src, dst, g, L, digit, jnext, st);
-        default: return launch_sweep_n<ES, S, 0>(ctx, src, dst, g, L, digit, jnext, st);
-    }
-}
-
-template <int ES>
-int launch_sweep(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L, uint32_t digit,
-                 unsigned long long* jnext, int xf, hipStream_t st) {
-    if (status32(g)) return launch_sweep_x<ES, uint32_t>(ctx, src, dst, g, L, digit, jnext, xf, st);
-    return launch_sweep_x<ES, uint64_t>(ctx, src, dst, g, L, digit, jnext, xf, st);
 }
 
 #define RSX_DISPATCH_ES(es, FN, ...)                           \
@@ -424,17 +133,23 @@ int hist_dispatch(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_
     RSX_DISPATCH_ES(L->elem_bytes, launch_hist, ctx, src, g, L, digit, J, st)
 }
 int sweep_dispatch(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L,
-                   uint32_t digit, unsigned long long* jnext, int xf, hipStream_t st) {
-    RSX_DISPATCH_ES(L->elem_bytes, launch_sweep, ctx, src, dst, g, L, digit, jnext, xf, st)
+                   uint32_t digit, const unsigned long long* J, unsigned long long* jnext, unsigned long long* jzero,
+                   int xf, hipStream_t st) {
+    RSX_DISPATCH_ES(L->elem_bytes, launch_sweep, ctx, src, dst, g, L, digit, J, jnext, jzero, xf, st)
 }
 
-template <int ES>
-int launch_segcopy(rsx_ctx* ctx, const void* src, void* dst, const uint64_t* so, const uint64_t* dof,
-                   const uint64_t* len, uint32_t nseg, hipStream_t st) {
-    const uint32_t bps = 8;
-    hipLaunchKernelGGL((rsx_segcopy_kernel<ES>), dim3(nseg * bps), dim3(256), 0, st,
-                       static_cast<const Elem<ES>*>(src), static_cast<Elem<ES>*>(dst), so, dof, len, nseg, bps);
+// the 256 digit totals of a count matrix -> d_counts
+int launch_totals(rsx_ctx* ctx, const RegionGeom& g, const unsigned long long* J, uint64_t* d_counts, hipStream_t st) {
+    LaunchTimer lt(ctx, RSX_PROF_SCAN, st);
+    hipLaunchKernelGGL(rsx_totals_kernel, dim3(1), dim3(RADIX), 0, st, J, g.num_regions, d_counts);
     RSX_HIP(hipGetLastError());
+    return RSX_OK;
+}
+
+// zeroes what a sort (or a lone pass) accumulates into: count matrices 0 and 1, every pass's
+// tickets and roll-call words -- one contiguous memset
+int zero_counters(rsx_ctx* ctx, hipStream_t st) {
+    RSX_HIP(hipMemsetAsync(ctx->aux + OFF_J0, 0, OFF_ZERO_END - OFF_J0, st));
     return RSX_OK;
 }
 
@@ -456,6 +171,59 @@ struct DeviceGuard {
         if (prev >= 0) (void)hipSetDevice(prev);
     }
 };
+
+// A kernel of this context gave up a bounded wait (the word is host-visible: no sync needed to see it).
+int pending_error(rsx_ctx* ctx) {
+    if (ctx->host_err && *reinterpret_cast<volatile uint32_t*>(ctx->host_err))
+        return fail(ctx, RSX_ERR_INTERNAL, "an earlier sort on this context gave up a device-side wait; its output is invalid (rsx_ctx_check clears the condition)");
+    return RSX_OK;
+}
+
+// body of rsx_sort_device; caller holds ctx->mu and has set the device
+int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const rsx_layout* L, hipStream_t st) {
+    int rc = pending_error(ctx);
+    if (rc) return rc;
+    rc = ensure_workspace(ctx, n, L, st);
+    if (rc) return rc;
+    Enqueue enq(ctx, st);
+    const uint32_t D = L->key_bytes;  // T::NUMBER_OF_DIGITS
+    const RegionGeom geom = make_geom(ctx, n, L->elem_bytes);
+    // count phase of pass 0 (mod.rs:90-109); later passes are counted by the sweep before them
+    rc = zero_counters(ctx, st);
+    if (rc) return rc;
+    rc = hist_dispatch(ctx, d_data, geom, L, 0, J_of(ctx, 0), st);
+    if (rc) return rc;
+    if (L->elem_bytes == 1 && !(ctx->options & OPT_GENERAL_BYTES)) {
+        // u8 / i8: the element is its digit, so the 256 counts ARE the sorted array (same bytes as
+        // the pass + copy-back of mod.rs:121-174 would leave): write the runs, skip scatter and copy
+        uint64_t* totals = reinterpret_cast<uint64_t*>(J_of(ctx, 1));
+        rc = launch_totals(ctx, geom, J_of(ctx, 0), totals, st);
+        if (rc) return rc;
+        LaunchTimer lt(ctx, RSX_PROF_OTHER, st);
+        const uint64_t chunks = (n + 15) / 16;
+        uint64_t blocks = (chunks + 255) / 256;
+        if (blocks > (uint64_t)ctx->num_cu * 16) blocks = (uint64_t)ctx->num_cu * 16;
+        hipLaunchKernelGGL(rsx_expand_bytes_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, static_cast<uint8_t*>(d_data),
+                           (uint64_t)n, totals, L->key_kind == RSX_KEY_SIGNED ? 0x80u : 0u);
+        RSX_HIP(hipGetLastError());
+        return RSX_OK;
+    }
+    // pass loop with ping-pong (mod.rs:84-89); the prefix phase (mod.rs:110-120) is the prologue of each sweep
+    for (uint32_t d = 0; d < D; ++d) {
+        const void* src = (d % 2 == 0) ? d_data : d_tmp;
+        void* dst = (d % 2 == 0) ? d_tmp : d_data;
+        unsigned long long* jnext = (d + 1 < D) ? J_of(ctx, (d + 1) % 3) : nullptr;
+        unsigned long long* jzero = (d + 2 < D) ? J_of(ctx, (d + 2) % 3) : nullptr;
+        const int xf = (d == 0 ? 1 : 0) | (d + 1 == D ? 2 : 0);  // key map on at the first, off at the last pass
+        ctx->pass_index = d;
+        ctx->pass_last = d + 1 == D;
+        rc = sweep_dispatch(ctx, src, dst, geom, L, d, J_of(ctx, d % 3), jnext, jzero, xf, st);  // mod.rs:121-168
+        if (rc) return rc;
+    }
+    if (D % 2 == 1)  // odd-D copy-back (mod.rs:170-174)
+        RSX_HIP(hipMemcpyAsync(d_data, d_tmp, n * (size_t)L->elem_bytes, hipMemcpyDeviceToDevice, st));
+    return RSX_OK;
+}
 
 }  // namespace
 
@@ -482,8 +250,14 @@ const char* rsx_last_error(const rsx_ctx* ctx) { return ctx ? ctx->err.c_str() :
 int rsx_ctx_create(int device, rsx_ctx** out) try {
     if (!out) return RSX_ERR_ARG;
     *out = nullptr;
+    const char* verbose = std::getenv("RSX_VERBOSE");
+    const bool loud = verbose && verbose[0] && verbose[0] != '0';
     int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return RSX_ERR_NODEVICE;
+    hipError_t he = hipGetDeviceCount(&count);
+    if (he != hipSuccess || count <= 0) {
+        if (loud) std::fprintf(stderr, "[rsx] hipGetDeviceCount: %s (count %d)\n", hipGetErrorString(he), count);
+        return RSX_ERR_NODEVICE;
+    }
     if (device < 0) {
         if (hipGetDevice(&device) != hipSuccess) return RSX_ERR_NODEVICE;
     }
@@ -491,12 +265,15 @@ int rsx_ctx_create(int device, rsx_ctx** out) try {
     rsx_ctx* ctx = new (std::nothrow) rsx_ctx();
     if (!ctx) return RSX_ERR_NOMEM;
     ctx->device = device;
+    if (loud) ctx->options |= OPT_VERBOSE;
+#ifdef RSX_TUNING  // timing ablations exist in tuning builds only (some give wrong output by design)
     if (const char* dbg = std::getenv("RSX_DEBUG")) ctx->dbg = (uint32_t)std::strtoul(dbg, nullptr, 0);
-    if (const char* h = std::getenv("RSX_HOT")) ctx->hot_lanes = (uint32_t)std::strtoul(h, nullptr, 0);
+#endif
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
         ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {  // code objects are gfx950-only
+            if (loud) std::fprintf(stderr, "[rsx] device %d is %s, not gfx950\n", device, prop.gcnArchName);
             delete ctx;
             return RSX_ERR_NODEVICE;
         }
@@ -511,10 +288,23 @@ int rsx_ctx_destroy(rsx_ctx* ctx) try {
     if (!ctx) return RSX_ERR_ARG;
     {
         DeviceGuard g(ctx->device);
+        if (ctx->busy && ctx->last_event) (void)hipEventSynchronize(ctx->last_event);
         if (ctx->status) (void)hipFree(ctx->status);
         if (ctx->aux) (void)hipFree(ctx->aux);
+        if (ctx->host_err) (void)hipHostFree(ctx->host_err);
+        if (ctx->last_event) (void)hipEventDestroy(ctx->last_event);
         for (void* p : ctx->host_buf)
             if (p) (void)hipFree(p);
+        for (void* p : ctx->pinned)
+            if (p) (void)hipHostFree(p);
+        for (hipStream_t s : ctx->copy_stream)
+            if (s) (void)hipStreamDestroy(s);
+        for (hipEvent_t e : ctx->copy_event)
+            if (e) (void)hipEventDestroy(e);
+        if (ctx->shard_q) (void)hipFree(ctx->shard_q);
+        if (ctx->shard_out) (void)hipFree(ctx->shard_out);
+        if (ctx->shard_hist) (void)hipFree(ctx->shard_hist);
+        if (ctx->shard_stream) (void)hipStreamDestroy(ctx->shard_stream);
         for (int k = 0; k < RSX_PROF_KINDS; ++k)
             for (auto& e : ctx->prof_pending[k]) ctx->prof_free.push_back(e);
         for (auto& e : ctx->prof_free) {
@@ -533,7 +323,7 @@ int rsx_ctx_reserve(rsx_ctx* ctx, size_t n, const rsx_layout* layout) try {
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard g(ctx->device);
-    return ensure_workspace(ctx, n, layout);
+    return ensure_workspace(ctx, n, layout, nullptr);
 } catch (...) {
     return RSX_ERR_NOMEM;
 }
@@ -543,11 +333,11 @@ int rsx_ctx_check(rsx_ctx* ctx, void* stream) try {
     std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard g(ctx->device);
     RSX_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
-    if (!ctx->aux) return RSX_OK;
-    uint32_t e = 0;
-    RSX_HIP(hipMemcpy(&e, error_of(ctx), sizeof e, hipMemcpyDeviceToHost));
-    if (e) {
-        (void)hipMemset(error_of(ctx), 0, sizeof e);
+    if (!ctx->host_err) return RSX_OK;
+    volatile uint32_t* e = reinterpret_cast<volatile uint32_t*>(ctx->host_err);
+    if (*e) {
+        if (ctx->busy) (void)hipEventSynchronize(ctx->last_event);  // nothing of this context may still be running
+        *e = 0;
         return fail(ctx, RSX_ERR_INTERNAL, "look-back spin gave up (device protocol error)");
     }
     return RSX_OK;
@@ -555,13 +345,76 @@ int rsx_ctx_check(rsx_ctx* ctx, void* stream) try {
     return RSX_ERR_HIP;
 }
 
-// Diagnostic counters of the sweep kernel (RSX_DEBUG & 0x100); not part of include/rsx.h.
-int rsx_debug_counters(rsx_ctx* ctx, unsigned long long* out8, int reset) try {
-    if (!ctx || !out8 || !ctx->aux) return RSX_ERR_ARG;
+int rsx_ctx_set_option(rsx_ctx* ctx, int option, uint64_t value) try {
+    if (!ctx) return RSX_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto flag = [&](uint32_t bit, bool on) { ctx->options = on ? (ctx->options | bit) : (ctx->options & ~bit); };
+    switch (option) {
+        case RSX_OPT_TILE_SCHEDULE:
+            if (value > 1) return fail(ctx, RSX_ERR_ARG, "RSX_OPT_TILE_SCHEDULE: 0 (roll call) or 1 (tickets)");
+            flag(OPT_DYNAMIC_TILES, value == 1);
+            return RSX_OK;
+        case RSX_OPT_RANKING:
+            if (value > 2) return fail(ctx, RSX_ERR_ARG, "RSX_OPT_RANKING: 0 (auto), 1 (ballots) or 2 (LDS atomics)");
+            flag(OPT_BALLOT_RANKS, value == 1);
+            flag(OPT_ATOMIC_RANKS, value == 2);
+            return RSX_OK;
+        case RSX_OPT_STATUS_SCOPE:
+            if (value > 1) return fail(ctx, RSX_ERR_ARG, "RSX_OPT_STATUS_SCOPE: 0 (auto) or 1 (agent)");
+            flag(OPT_AGENT_STATUS, value == 1);
+            return RSX_OK;
+        case RSX_OPT_XCD_MAJOR:
+            if (value > 1) return fail(ctx, RSX_ERR_ARG, "RSX_OPT_XCD_MAJOR: 0 or 1");
+            flag(OPT_NO_XCD_MAJOR, value == 0);
+            return RSX_OK;
+        case RSX_OPT_BYTE_COUNTING:
+            if (value > 1) return fail(ctx, RSX_ERR_ARG, "RSX_OPT_BYTE_COUNTING: 0 or 1");
+            flag(OPT_GENERAL_BYTES, value == 0);
+            return RSX_OK;
+        case RSX_OPT_MAX_REGIONS:
+            if (value > (uint64_t)MAX_REGIONS) return fail(ctx, RSX_ERR_ARG, "RSX_OPT_MAX_REGIONS: 0 (default) .. 32");
+            ctx->max_regions = (uint32_t)value;
+            return RSX_OK;
+        case RSX_OPT_HOT_LANES:
+            if (value < 2 || value > 65) return fail(ctx, RSX_ERR_ARG, "RSX_OPT_HOT_LANES: 2 .. 65");
+            ctx->hot_lanes = (uint32_t)value;
+            return RSX_OK;
+        case RSX_OPT_VERBOSE:
+            flag(OPT_VERBOSE, value != 0);
+            return RSX_OK;
+        default:
+            return fail(ctx, RSX_ERR_ARG, "unknown option");
+    }
+} catch (...) {
+    return RSX_ERR_NOMEM;
+}
+
+int rsx_ctx_get_info(rsx_ctx* ctx, int what, uint64_t* out) try {
+    if (!ctx || !out) return RSX_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    if (what == RSX_INFO_RANK_ATOMIC || what == RSX_INFO_L2_LOCAL) {
+        int rc = ensure_aux(ctx, nullptr);  // runs the self-tests on first use
+        if (rc) return rc;
+    }
+    switch (what) {
+        case RSX_INFO_RANK_ATOMIC: *out = ctx->rank_atomic ? 1 : 0; return RSX_OK;
+        case RSX_INFO_L2_LOCAL: *out = ctx->l2_local ? 1 : 0; return RSX_OK;
+        case RSX_INFO_NUM_CU: *out = (uint64_t)ctx->num_cu; return RSX_OK;
+        case RSX_INFO_DEVICE: *out = (uint64_t)ctx->device; return RSX_OK;
+        default: return fail(ctx, RSX_ERR_ARG, "unknown info id");
+    }
+} catch (...) {
+    return RSX_ERR_HIP;
+}
+
+// Diagnostic counters of the sweep kernel (RSX_TUNING builds, RSX_DEBUG & 0x100); not part of include/rsx.h.
+int rsx_debug_counters(rsx_ctx* ctx, unsigned long long* out128, int reset) try {
+    if (!ctx || !out128 || !ctx->aux) return RSX_ERR_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard g(ctx->device);
     RSX_HIP(hipDeviceSynchronize());
-    RSX_HIP(hipMemcpy(out8, ctx->aux + OFF_DBG, 1024, hipMemcpyDeviceToHost));  // caller passes 128 u64
+    RSX_HIP(hipMemcpy(out128, ctx->aux + OFF_DBG, 1024, hipMemcpyDeviceToHost));  // caller passes 128 u64
     if (reset) RSX_HIP(hipMemset(ctx->aux + OFF_DBG, 0, 1024));
     return RSX_OK;
 } catch (...) {
@@ -617,48 +470,77 @@ int rsx_sort_device(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const rsx
     std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard g(ctx->device);
     if (!g.ok) return fail(ctx, RSX_ERR_NODEVICE, "hipSetDevice failed");
-    rc = ensure_workspace(ctx, n, L);
-    if (rc) return rc;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const uint32_t D = L->key_bytes;  // T::NUMBER_OF_DIGITS
-    const RegionGeom geom = make_geom(n, L->elem_bytes);
-    // count phase of pass 0 (mod.rs:90-109); later passes are counted by the sweep before them
-    rc = hist_dispatch(ctx, d_data, geom, L, 0, J_of(ctx, 0), st);
-    if (rc) return rc;
-    if (L->elem_bytes == 1 && !(ctx->dbg & 0x40000u)) {
-        // u8 / i8: the element is its digit, so the 256 counts ARE the sorted array (same bytes as
-        // the pass + copy-back of mod.rs:121-174 would leave): write the runs, skip scatter and copy
-        uint64_t* totals = reinterpret_cast<uint64_t*>(J_of(ctx, 1));
-        rc = launch_prefix(ctx, geom, J_of(ctx, 0), nullptr, totals, st);
-        if (rc) return rc;
-        LaunchTimer lt(ctx, RSX_PROF_OTHER, st);
-        const uint64_t chunks = (n + 15) / 16;
-        uint64_t blocks = (chunks + 255) / 256;
-        if (blocks > (uint64_t)ctx->num_cu * 16) blocks = (uint64_t)ctx->num_cu * 16;
-        hipLaunchKernelGGL(rsx_expand_bytes_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, static_cast<uint8_t*>(d_data),
-                           (uint64_t)n, totals, L->key_kind == RSX_KEY_SIGNED ? 0x80u : 0u);
-        RSX_HIP(hipGetLastError());
-        return RSX_OK;
-    }
-    // pass loop with ping-pong (mod.rs:84-89)
-    for (uint32_t d = 0; d < D; ++d) {
-        const void* src = (d % 2 == 0) ? d_data : d_tmp;
-        void* dst = (d % 2 == 0) ? d_tmp : d_data;
-        unsigned long long* jnext = (d + 1 < D) ? J_of(ctx, (d + 1) & 1) : nullptr;
-        rc = launch_prefix(ctx, geom, J_of(ctx, d & 1), jnext, nullptr, st);  // mod.rs:110-120
-        if (rc) return rc;
-        const int xf = (d == 0 ? 1 : 0) | (d + 1 == D ? 2 : 0);  // key map on at the first, off at the last pass
-        ctx->pass_index = d;
-        ctx->pass_last = d + 1 == D;
-        rc = sweep_dispatch(ctx, src, dst, geom, L, d, jnext, xf, st);  // mod.rs:121-168
-        if (rc) return rc;
-    }
-    if (D % 2 == 1)  // odd-D copy-back (mod.rs:170-174)
-        RSX_HIP(hipMemcpyAsync(d_data, d_tmp, n * (size_t)L->elem_bytes, hipMemcpyDeviceToDevice, st));
-    return RSX_OK;
+    return sort_device_locked(ctx, d_data, d_tmp, n, L, static_cast<hipStream_t>(stream));
 } catch (...) {
     return RSX_ERR_HIP;
 }
+
+// Host drop-in.  The slice is pageable memory; a pageable hipMemcpy is staged by the runtime through
+// one bounce buffer by one thread (measured 27 GB/s each way on the 4 GB rung of the reference's
+// ladder).  Here the copy is a pipeline of HOST_CHUNK pieces over a ring of pinned buffers: worker
+// threads fill (drain) the pinned chunks with memcpy while the DMA engine moves the previous ones,
+// H2D and D2H each on its own stream; the count kernel of pass 0 cannot start before the last
+// chunk, so the sort itself is not overlapped (8 ms of ~150).
+namespace {
+constexpr size_t HOST_CHUNK = 32u << 20;
+constexpr int HOST_RING = 4;
+
+void par_memcpy(char* dst, const char* src, size_t bytes, int threads) {
+    if (bytes < (4u << 20) || threads <= 1) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    std::vector<std::thread> th;
+    const size_t per = ((bytes / threads) + 4095) & ~(size_t)4095;
+    for (int t = 0; t < threads; ++t) {
+        const size_t off = (size_t)t * per;
+        if (off >= bytes) break;
+        const size_t len = bytes - off < per ? bytes - off : per;
+        th.emplace_back([=] { std::memcpy(dst + off, src + off, len); });
+    }
+    for (auto& x : th) x.join();
+}
+
+int host_pipeline(rsx_ctx* ctx, char* host, char* dev, size_t bytes, bool to_device) {
+    for (int i = 0; i < HOST_RING; ++i) {
+        if (!ctx->pinned[i]) RSX_HIP(hipHostMalloc(&ctx->pinned[i], HOST_CHUNK, hipHostMallocDefault));
+        if (!ctx->copy_event[i]) RSX_HIP(hipEventCreateWithFlags(&ctx->copy_event[i], hipEventDisableTiming));
+    }
+    if (!ctx->copy_stream[0]) RSX_HIP(hipStreamCreateWithFlags(&ctx->copy_stream[0], hipStreamNonBlocking));
+    hipStream_t cs = ctx->copy_stream[0];
+    const int threads = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency() / 2));
+    const size_t chunks = (bytes + HOST_CHUNK - 1) / HOST_CHUNK;
+    if (to_device) {
+        for (size_t c = 0; c < chunks; ++c) {
+            const int slot = (int)(c % HOST_RING);
+            const size_t off = c * HOST_CHUNK, len = std::min(HOST_CHUNK, bytes - off);
+            if (c >= (size_t)HOST_RING) RSX_HIP(hipEventSynchronize(ctx->copy_event[slot]));  // slot's DMA done
+            par_memcpy(static_cast<char*>(ctx->pinned[slot]), host + off, len, threads);
+            RSX_HIP(hipMemcpyAsync(dev + off, ctx->pinned[slot], len, hipMemcpyHostToDevice, cs));
+            RSX_HIP(hipEventRecord(ctx->copy_event[slot], cs));
+        }
+        RSX_HIP(hipStreamSynchronize(cs));
+    } else {
+        // DMA runs HOST_RING chunks ahead of the draining memcpy
+        for (size_t c = 0; c < chunks + HOST_RING; ++c) {
+            if (c >= (size_t)HOST_RING) {  // drain chunk c - HOST_RING
+                const size_t k = c - HOST_RING;
+                const int slot = (int)(k % HOST_RING);
+                const size_t off = k * HOST_CHUNK, len = std::min(HOST_CHUNK, bytes - off);
+                RSX_HIP(hipEventSynchronize(ctx->copy_event[slot]));
+                par_memcpy(host + off, static_cast<const char*>(ctx->pinned[slot]), len, threads);
+            }
+            if (c < chunks) {
+                const int slot = (int)(c % HOST_RING);
+                const size_t off = c * HOST_CHUNK, len = std::min(HOST_CHUNK, bytes - off);
+                RSX_HIP(hipMemcpyAsync(ctx->pinned[slot], dev + off, len, hipMemcpyDeviceToHost, cs));
+                RSX_HIP(hipEventRecord(ctx->copy_event[slot], cs));
+            }
+        }
+    }
+    return RSX_OK;
+}
+}  // namespace
 
 int rsx_sort_host(rsx_ctx* ctx, void* data, size_t n, const rsx_layout* L) try {
     int rc = check_common(ctx, L);
@@ -666,33 +548,35 @@ int rsx_sort_host(rsx_ctx* ctx, void* data, size_t n, const rsx_layout* L) try {
     if (n <= 1) return RSX_OK;
     if (!data) return fail(ctx, RSX_ERR_ARG, "null host pointer");
     const size_t bytes = n * (size_t)L->elem_bytes;
-    {
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        DeviceGuard g(ctx->device);
-        if (bytes > ctx->host_bytes) {
-            for (void*& p : ctx->host_buf) {
-                if (p) (void)hipFree(p);
-                p = nullptr;
-            }
-            ctx->host_bytes = 0;
-            for (void*& p : ctx->host_buf) {
-                hipError_t e = hipMalloc(&p, bytes);
-                if (e != hipSuccess) return fail(ctx, RSX_ERR_NOMEM, "staging hipMalloc", e);
-            }
-            ctx->host_bytes = bytes;
+    std::lock_guard<std::mutex> lk(ctx->mu);  // one lock across copy-in, sort and copy-out: the staging buffers are the context's
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return fail(ctx, RSX_ERR_NODEVICE, "hipSetDevice failed");
+    if (bytes > ctx->host_bytes) {
+        if (ctx->busy) RSX_HIP(hipEventSynchronize(ctx->last_event));
+        for (void*& p : ctx->host_buf) {
+            if (p) (void)hipFree(p);
+            p = nullptr;
         }
-        RSX_HIP(hipMemcpy(ctx->host_buf[0], data, bytes, hipMemcpyHostToDevice));
+        ctx->host_bytes = 0;
+        for (void*& p : ctx->host_buf) {
+            hipError_t e = hipMalloc(&p, bytes);
+            if (e != hipSuccess) return fail(ctx, RSX_ERR_NOMEM, "staging hipMalloc", e);
+        }
+        ctx->host_bytes = bytes;
     }
-    rc = rsx_sort_device(ctx, ctx->host_buf[0], ctx->host_buf[1], n, L, nullptr);
+    if (ctx->busy) RSX_HIP(hipEventSynchronize(ctx->last_event));  // an earlier device sort may still use the workspace
+    rc = host_pipeline(ctx, static_cast<char*>(data), static_cast<char*>(ctx->host_buf[0]), bytes, true);
     if (rc) return rc;
-    rc = rsx_ctx_check(ctx, nullptr);
+    hipStream_t st = ctx->copy_stream[0];
+    rc = sort_device_locked(ctx, ctx->host_buf[0], ctx->host_buf[1], n, L, st);
     if (rc) return rc;
-    {
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        DeviceGuard g(ctx->device);
-        RSX_HIP(hipMemcpy(data, ctx->host_buf[0], bytes, hipMemcpyDeviceToHost));
+    RSX_HIP(hipStreamSynchronize(st));
+    rc = pending_error(ctx);
+    if (rc) {
+        *reinterpret_cast<volatile uint32_t*>(ctx->host_err) = 0;
+        return fail(ctx, RSX_ERR_INTERNAL, "look-back spin gave up (device protocol error)");
     }
-    return RSX_OK;
+    return host_pipeline(ctx, static_cast<char*>(data), static_cast<char*>(ctx->host_buf[0]), bytes, false);
 } catch (...) {
     return RSX_ERR_HIP;
 }
@@ -710,15 +594,41 @@ int rsx_histogram_device(rsx_ctx* ctx, const void* d_src, size_t n, const rsx_la
         return RSX_OK;
     }
     if (!d_src || !aligned(d_src, elem_align(L->elem_bytes))) return fail(ctx, RSX_ERR_ARG, "bad source pointer");
-    rc = ensure_workspace(ctx, n, L);
+    rc = ensure_workspace(ctx, n, L, st);
     if (rc) return rc;
-    const RegionGeom geom = make_geom(n, L->elem_bytes);
+    Enqueue enq(ctx, st);
+    const RegionGeom geom = make_geom(ctx, n, L->elem_bytes);
+    rc = zero_counters(ctx, st);
+    if (rc) return rc;
     rc = hist_dispatch(ctx, d_src, geom, L, digit, J_of(ctx, 0), st);
     if (rc) return rc;
-    return launch_prefix(ctx, geom, J_of(ctx, 0), nullptr, d_hist, st);  // column sums -> d_hist
+    return launch_totals(ctx, geom, J_of(ctx, 0), d_hist, st);  // column sums -> d_hist
 } catch (...) {
     return RSX_ERR_HIP;
 }
+
+namespace {
+int partition_locked(rsx_ctx* ctx, const void* d_src, void* d_dst, size_t n, const rsx_layout* L, uint32_t digit,
+                     uint64_t* d_hist, hipStream_t st) {
+    int rc = pending_error(ctx);
+    if (rc) return rc;
+    rc = ensure_workspace(ctx, n, L, st);
+    if (rc) return rc;
+    Enqueue enq(ctx, st);
+    const RegionGeom geom = make_geom(ctx, n, L->elem_bytes);
+    rc = zero_counters(ctx, st);
+    if (rc) return rc;
+    rc = hist_dispatch(ctx, d_src, geom, L, digit, J_of(ctx, 0), st);
+    if (rc) return rc;
+    if (d_hist) {
+        rc = launch_totals(ctx, geom, J_of(ctx, 0), d_hist, st);
+        if (rc) return rc;
+    }
+    ctx->pass_index = 0;
+    ctx->pass_last = true;
+    return sweep_dispatch(ctx, d_src, d_dst, geom, L, digit, J_of(ctx, 0), nullptr, nullptr, 3, st);  // a lone pass maps and unmaps
+}
+}  // namespace
 
 int rsx_partition_device(rsx_ctx* ctx, const void* d_src, void* d_dst, size_t n, const rsx_layout* L,
                          uint32_t digit, uint64_t* d_hist, void* stream) try {
@@ -735,16 +645,7 @@ int rsx_partition_device(rsx_ctx* ctx, const void* d_src, void* d_dst, size_t n,
     const uint32_t al = elem_align(L->elem_bytes);
     if (!d_src || !d_dst || !aligned(d_src, al) || !aligned(d_dst, al))
         return fail(ctx, RSX_ERR_ARG, "bad device pointer");
-    rc = ensure_workspace(ctx, n, L);
-    if (rc) return rc;
-    const RegionGeom geom = make_geom(n, L->elem_bytes);
-    rc = hist_dispatch(ctx, d_src, geom, L, digit, J_of(ctx, 0), st);
-    if (rc) return rc;
-    rc = launch_prefix(ctx, geom, J_of(ctx, 0), nullptr, d_hist, st);
-    if (rc) return rc;
-    ctx->pass_index = 0;
-    ctx->pass_last = true;
-    return sweep_dispatch(ctx, d_src, d_dst, geom, L, digit, nullptr, 3, st);  // a lone pass maps and unmaps
+    return partition_locked(ctx, d_src, d_dst, n, L, digit, d_hist, st);
 } catch (...) {
     return RSX_ERR_HIP;
 }
@@ -764,28 +665,6 @@ int rsx_segmented_copy_device(rsx_ctx* ctx, const void* d_src, void* d_dst, uint
     return RSX_ERR_HIP;
 }
 
-int rsx_extract_keys_device(rsx_ctx* ctx, const void* d_src, size_t n, const rsx_layout* L, int64_t* d_keys,
-                            void* stream) try {
-    if (!ctx) return RSX_ERR_ARG;
-    if (!layout_ok(L)) return fail(ctx, RSX_ERR_ARG, "invalid rsx_layout");
-    if (L->key_bytes > 8) return fail(ctx, RSX_ERR_UNSUPPORTED, "keys wider than 8 bytes have no 64-bit form");
-    if (n == 0) return RSX_OK;
-    if (!d_src || !d_keys) return fail(ctx, RSX_ERR_ARG, "null pointer");
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    DeviceGuard g(ctx->device);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    uint64_t blocks = (n + 255) / 256;
-    const uint64_t cap = (uint64_t)ctx->num_cu * 16;
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(rsx_extract_keys_kernel, dim3((uint32_t)blocks), dim3(256), 0, st,
-                       static_cast<const uint8_t*>(d_src), (uint64_t)n, L->elem_bytes, L->key_offset, L->key_bytes,
-                       L->key_kind, reinterpret_cast<long long*>(d_keys));
-    RSX_HIP(hipGetLastError());
-    return RSX_OK;
-} catch (...) {
-    return RSX_ERR_HIP;
-}
-
 int rsx_bounds_device(rsx_ctx* ctx, const void* d_sorted, size_t n, const rsx_layout* L, const uint64_t* d_queries,
                       uint32_t nq, uint64_t* d_out, void* stream) try {
     if (!ctx) return RSX_ERR_ARG;
@@ -796,102 +675,143 @@ int rsx_bounds_device(rsx_ctx* ctx, const void* d_sorted, size_t n, const rsx_la
     DeviceGuard g(ctx->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(rsx_bounds_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, static_cast<const uint8_t*>(d_sorted),
-                       (uint64_t)n, L->elem_bytes, L->key_offset, L->key_bytes, L->key_kind, d_queries, nq, d_out);
+                       (uint64_t)n, L->elem_bytes, L->key_offset, L->key_bytes, L->key_kind, d_queries, nq, d_out,
+                       static_cast<const uint64_t*>(nullptr));
     RSX_HIP(hipGetLastError());
     return RSX_OK;
 } catch (...) {
     return RSX_ERR_HIP;
 }
 
-// ---- multi-GPU, one process: one exchange between two local sorts ------------------------------
+// ---- multi-GPU, one process ---------------------------------------------------------------------
 // The G slices are "chunks" in the sense of mod.rs:66-70; the result is what the reference would
-// produce on their concatenation.  Schedule: (1) every device sorts its slice; (2) the G-1 slice
-// boundaries of the sorted whole are located exactly -- boundary h is the key K_h with
-// less(K_h) <= T_h < less_or_equal(K_h) over all slices, found digit by digit (256 candidates per
-// step, counted by binary search in every sorted slice), ties on K_h dealt out in slice order;
-// (3) each device pushes the G ranges of its slice to their owners over xGMI, ordered by source
-// slice at the receiver; (4) a second stable local sort merges the G sorted runs.  Stability: equal
-// keys stay in (source slice, local index) order through (3), and (4) is stable.
-int rsx_sort_sharded(rsx_ctx* const* ctxs, uint32_t ndev, void* const* d_slices, void* const* d_tmps,
-                     const size_t* n_per_dev, const rsx_layout* L) try {
-    if (!ctxs || ndev == 0 || !ctxs[0]) return RSX_ERR_ARG;
-    rsx_ctx* ctx = ctxs[0];  // carries the error text
-    if (!d_slices || !d_tmps || !n_per_dev) return fail(ctx, RSX_ERR_ARG, "null table");
-    const uint32_t G = ndev;
-    if (G > 64) return fail(ctx, RSX_ERR_ARG, "more than 64 slices");
-    for (uint32_t g = 0; g < G; ++g) {
-        if (!ctxs[g]) return fail(ctx, RSX_ERR_ARG, "null context in table");
-        int rc = check_common(ctxs[g], L);
-        if (rc) return rc == RSX_ERR_ARG ? fail(ctx, rc, "invalid rsx_layout") : fail(ctx, rc, "element size has no device kernel");
-        if (n_per_dev[g] && (!d_slices[g] || !d_tmps[g])) return fail(ctx, RSX_ERR_ARG, "null device pointer");
-        for (uint32_t h = 0; h < g; ++h)
-            if (ctxs[h] == ctxs[g]) return fail(ctx, RSX_ERR_ARG, "one context per slice");
-    }
-    const size_t es = L->elem_bytes;
-    // (1) local sorts, all devices at once
-    auto sort_all = [&]() -> int {
-        for (uint32_t g = 0; g < G; ++g) {
-            int rc = rsx_sort_device(ctxs[g], d_slices[g], d_tmps[g], n_per_dev[g], L, nullptr);
-            if (rc) return g ? fail(ctx, rc, rsx_last_error(ctxs[g])) : rc;
-        }
-        for (uint32_t g = 0; g < G; ++g) {
-            int rc = rsx_ctx_check(ctxs[g], nullptr);
-            if (rc) return g ? fail(ctx, rc, rsx_last_error(ctxs[g])) : rc;
-        }
-        return RSX_OK;
-    };
-    int rc = sort_all();
-    if (rc || G == 1) return rc;
+// produce on their concatenation.  Two schedules, both moving every element across devices ONCE:
+//
+//  exchange first (default): (1) every device makes one stable partition pass of its slice by the
+//    MOST significant digit (count + scatter of mod.rs:90-168 for that digit) and reports the 256
+//    counts; (2) the host lays the G x 256 counts out in global order: a slice boundary that falls
+//    between two buckets needs nothing more; for a boundary inside bucket v, every device sorts
+//    its piece of bucket v (a small local sort) and the exact cut is found as in the other
+//    schedule, inside those pieces only; (3) each device pushes, per owner, ONE contiguous range of
+//    its partitioned slice over xGMI, ordered by source slice at the receiver; (4) ONE local sort.
+//    Work per element: 1 + D passes (plus the boundary buckets: 1/256 of the data per boundary for
+//    spread-out keys; all of it when one top digit holds everything -- then this schedule costs
+//    what the other does).
+//  sort first: (1) every device sorts its slice; (2) the G-1 boundaries are located exactly by a
+//    256-way search per digit, counted by binary search in every sorted slice; (3) exchange;
+//    (4) a second stable local sort merges the G sorted runs.  2 D passes per element.
+//
+// Stability in both: equal keys stay in (source slice, local index) order through the exchange --
+// ties on a boundary key are dealt out in slice order -- and the final local sort is stable.
+namespace {
 
-    std::vector<uint64_t> bounds(G + 1, 0);
-    for (uint32_t g = 0; g < G; ++g) bounds[g + 1] = bounds[g] + n_per_dev[g];
-    const uint32_t nb = G - 1;
-    const uint32_t nq_max = nb * RADIX;
+struct Shard {
+    rsx_ctx* c;
+    char* data;
+    char* tmp;
+    size_t n;
+};
 
-    // per-device query / answer buffers
-    struct Scratch {
-        rsx_ctx* c = nullptr;
-        uint64_t* q = nullptr;
-        uint64_t* out = nullptr;
-        ~Scratch() {
-            if (!c) return;
-            DeviceGuard g(c->device);
-            if (q) (void)hipFree(q);
-            if (out) (void)hipFree(out);
-        }
-    };
-    std::vector<Scratch> scr(G);
-    for (uint32_t g = 0; g < G; ++g) {
-        DeviceGuard dg(ctxs[g]->device);
-        if (!dg.ok) return fail(ctx, RSX_ERR_NODEVICE, "hipSetDevice failed");
-        scr[g].c = ctxs[g];
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&scr[g].q), (size_t)nq_max * 2 * sizeof(uint64_t));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&scr[g].out), (size_t)nq_max * 2 * sizeof(uint64_t));
-        if (e != hipSuccess) return fail(ctx, RSX_ERR_NOMEM, "splitter scratch hipMalloc", e);
+std::mutex g_peer_mu;
+bool g_peer_on[64][64];
+
+int shard_prepare(rsx_ctx* ctx0, rsx_ctx* ctx) {
+    DeviceGuard dg(ctx->device);
+    if (!dg.ok) return fail(ctx0, RSX_ERR_NODEVICE, "hipSetDevice failed");
+    hipError_t e = hipSuccess;
+    if (!ctx->shard_stream) e = hipStreamCreateWithFlags(&ctx->shard_stream, hipStreamNonBlocking);
+    const size_t qbytes = (size_t)64 * RADIX * 4 * sizeof(uint64_t);  // queries: (lo, hi) + (begin, end)
+    if (e == hipSuccess && !ctx->shard_q) e = hipMalloc(reinterpret_cast<void**>(&ctx->shard_q), qbytes);
+    if (e == hipSuccess && !ctx->shard_out) e = hipMalloc(reinterpret_cast<void**>(&ctx->shard_out), qbytes / 2);
+    if (e == hipSuccess && !ctx->shard_hist) e = hipMalloc(reinterpret_cast<void**>(&ctx->shard_hist), RADIX * sizeof(uint64_t));
+    if (e == hipSuccess && !ctx->shard_host) e = hipHostMalloc(reinterpret_cast<void**>(&ctx->shard_host), qbytes / 2 + RADIX * sizeof(uint64_t), hipHostMallocDefault);
+    if (e != hipSuccess) return fail(ctx0, RSX_ERR_NOMEM, "multi-GPU scratch allocation", e);
+    return RSX_OK;
+}
+
+void enable_peer(int from, int to) {  // direct xGMI writes where the topology allows; the copies work either way
+    if (from == to || from >= 64 || to >= 64) return;
+    std::lock_guard<std::mutex> lk(g_peer_mu);
+    if (g_peer_on[from][to]) return;
+    g_peer_on[from][to] = true;
+    DeviceGuard dg(from);
+    if (hipDeviceEnablePeerAccess(to, 0) != hipSuccess) (void)hipGetLastError();
+}
+
+int sync_all(rsx_ctx* ctx, const std::vector<Shard>& sh) {
+    for (const Shard& s : sh) {
+        DeviceGuard dg(s.c->device);
+        RSX_HIP(hipStreamSynchronize(s.c->shard_stream));
     }
-    // counts[g][0..nq) = elements < Q on slice g, counts[g][nq..2nq) = elements <= Q
-    std::vector<std::vector<uint64_t>> counts(G, std::vector<uint64_t>((size_t)nq_max * 2));
-    auto ask = [&](const std::vector<uint64_t>& q, uint32_t nq) -> int {
+    for (size_t g = 0; g < sh.size(); ++g) {
+        std::lock_guard<std::mutex> lk(sh[g].c->mu);
+        int rc = pending_error(sh[g].c);
+        if (rc) {
+            *reinterpret_cast<volatile uint32_t*>(sh[g].c->host_err) = 0;
+            return fail(ctx, RSX_ERR_INTERNAL, "look-back spin gave up on one of the slices");
+        }
+    }
+    return RSX_OK;
+}
+
+// local sort of `n` elements at `data` (scratch `tmp`) on the slice's own stream, not synchronised
+int sort_async(rsx_ctx* ctx0, rsx_ctx* c, void* data, void* tmp, size_t n, const rsx_layout* L) {
+    if (n <= 1) return RSX_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    DeviceGuard dg(c->device);
+    int rc = sort_device_locked(c, data, tmp, n, L, c->shard_stream);
+    if (rc && c != ctx0) return fail(ctx0, rc, c->err.c_str());
+    return rc;
+}
+
+struct Range {
+    uint64_t beg, end;
+};
+
+// Exact cuts inside sorted ranges.  For boundary b, slice g holds a range rng[b][g] of its buffer
+// buf[g] that is sorted by mapped key; the digits above `top_digit` of the boundary key are known
+// (pre_lo/pre_hi[b]).  rank[b] elements of the union of the ranges lie below the cut in the global
+// order (key, slice, index).  cut[b][g] = how many of rng[b][g]'s elements lie below it.
+// Digit by digit from `top_digit` down: 256 candidate keys per boundary, counted by binary search
+// in every range (rsx_bounds_kernel), all devices at once, one host round trip per digit.
+int find_cuts(rsx_ctx* ctx, const std::vector<Shard>& sh, const std::vector<char*>& buf, const rsx_layout* L,
+              const std::vector<std::vector<Range>>& rng, const std::vector<uint64_t>& rank, int top_digit,
+              std::vector<uint64_t> pre_lo, std::vector<uint64_t> pre_hi, std::vector<std::vector<uint64_t>>& cut) {
+    const uint32_t G = (uint32_t)sh.size();
+    const uint32_t nb = (uint32_t)rank.size();
+    cut.assign(nb, std::vector<uint64_t>(G, 0));
+    if (nb == 0) return RSX_OK;
+    if (nb > 64) return fail(ctx, RSX_ERR_ARG, "more than 64 boundaries");
+    std::vector<uint64_t> q((size_t)nb * RADIX * 4);
+    auto ask = [&](uint32_t per) -> int {  // `per` candidates per boundary are in q; answers land in shard_host
+        const uint32_t nq = nb * per;
         for (uint32_t g = 0; g < G; ++g) {
-            std::lock_guard<std::mutex> lk(ctxs[g]->mu);
-            DeviceGuard dg(ctxs[g]->device);
-            RSX_HIP(hipMemcpyAsync(scr[g].q, q.data(), (size_t)nq * 2 * sizeof(uint64_t), hipMemcpyHostToDevice, nullptr));
-            hipLaunchKernelGGL(rsx_bounds_kernel, dim3((nq + 255) / 256), dim3(256), 0, nullptr,
-                               static_cast<const uint8_t*>(d_slices[g]), (uint64_t)n_per_dev[g], L->elem_bytes,
-                               L->key_offset, L->key_bytes, L->key_kind, scr[g].q, nq, scr[g].out);
+            rsx_ctx* c = sh[g].c;
+            std::lock_guard<std::mutex> lk(c->mu);
+            DeviceGuard dg(c->device);
+            // queries: nq x (lo, hi), then nq x (begin, end) -- the ranges differ per slice
+            std::vector<uint64_t>& stage = c->shard_stage;
+            stage.resize((size_t)nq * 4);
+            for (uint32_t i = 0; i < nq; ++i) {
+                stage[2 * i] = q[2 * i];
+                stage[2 * i + 1] = q[2 * i + 1];
+                stage[(size_t)2 * nq + 2 * i] = rng[i / per][g].beg;
+                stage[(size_t)2 * nq + 2 * i + 1] = rng[i / per][g].end;
+            }
+            RSX_HIP(hipMemcpyAsync(c->shard_q, stage.data(), (size_t)nq * 4 * sizeof(uint64_t), hipMemcpyHostToDevice, c->shard_stream));
+            hipLaunchKernelGGL(rsx_bounds_kernel, dim3((nq + 255) / 256), dim3(256), 0, c->shard_stream,
+                               reinterpret_cast<const uint8_t*>(buf[g]), (uint64_t)sh[g].n, L->elem_bytes, L->key_offset,
+                               L->key_bytes, L->key_kind, c->shard_q, nq, c->shard_out, c->shard_q + (size_t)2 * nq);
             RSX_HIP(hipGetLastError());
+            RSX_HIP(hipMemcpyAsync(c->shard_host, c->shard_out, (size_t)nq * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->shard_stream));
         }
         for (uint32_t g = 0; g < G; ++g) {
-            std::lock_guard<std::mutex> lk(ctxs[g]->mu);
-            DeviceGuard dg(ctxs[g]->device);
-            RSX_HIP(hipMemcpy(counts[g].data(), scr[g].out, (size_t)nq * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            DeviceGuard dg(sh[g].c->device);
+            RSX_HIP(hipStreamSynchronize(sh[g].c->shard_stream));
         }
         return RSX_OK;
     };
-
-    // (2) splitters, most significant digit first
-    std::vector<uint64_t> pre_lo(nb, 0), pre_hi(nb, 0), q((size_t)nq_max * 2);
-    for (int digit = (int)L->key_bytes - 1; digit >= 0; --digit) {
+    for (int digit = top_digit; digit >= 0; --digit) {
         for (uint32_t b = 0; b < nb; ++b)
             for (uint32_t j = 0; j < RADIX; ++j) {
                 uint64_t lo = pre_lo[b], hi = pre_hi[b];
@@ -900,15 +820,14 @@ int rsx_sort_sharded(rsx_ctx* const* ctxs, uint32_t ndev, void* const* d_slices,
                 q[2 * ((size_t)b * RADIX + j)] = lo;
                 q[2 * ((size_t)b * RADIX + j) + 1] = hi;
             }
-        rc = ask(q, nq_max);
+        int rc = ask(RADIX);
         if (rc) return rc;
         for (uint32_t b = 0; b < nb; ++b) {
-            // largest candidate whose global "less" count does not exceed the boundary
-            uint32_t pick = 0;
+            uint32_t pick = 0;  // largest candidate whose global "less" count does not exceed the rank
             for (uint32_t j = 0; j < RADIX; ++j) {
                 uint64_t less = 0;
-                for (uint32_t g = 0; g < G; ++g) less += counts[g][(size_t)b * RADIX + j];
-                if (less <= bounds[b + 1]) pick = j;  // monotone in j
+                for (uint32_t g = 0; g < G; ++g) less += sh[g].c->shard_host[(size_t)b * RADIX + j];
+                if (less <= rank[b]) pick = j;  // monotone in j
             }
             if (digit < 8) pre_lo[b] |= (uint64_t)pick << (8 * digit);
             else pre_hi[b] |= (uint64_t)pick << (8 * (digit - 8));
@@ -918,67 +837,212 @@ int rsx_sort_sharded(rsx_ctx* const* ctxs, uint32_t ndev, void* const* d_slices,
         q[2 * b] = pre_lo[b];
         q[2 * b + 1] = pre_hi[b];
     }
-    rc = ask(q, nb);
+    int rc = ask(1);
     if (rc) return rc;
-    // split[g][h] = first element of slice g that goes to owner h
-    std::vector<std::vector<uint64_t>> split(G, std::vector<uint64_t>(G + 1, 0));
-    for (uint32_t g = 0; g < G; ++g) split[g][G] = n_per_dev[g];
     for (uint32_t b = 0; b < nb; ++b) {
         uint64_t less_total = 0;
-        for (uint32_t g = 0; g < G; ++g) less_total += counts[g][b];
-        uint64_t need = bounds[b + 1] - less_total;  // elements equal to K_b that go below the boundary
-        for (uint32_t g = 0; g < G; ++g) {            // ties: lower slice first (stability)
-            const uint64_t less = counts[g][b], eq = counts[g][nb + b] - less;
+        for (uint32_t g = 0; g < G; ++g) less_total += sh[g].c->shard_host[b];
+        if (less_total > rank[b]) return fail(ctx, RSX_ERR_INTERNAL, "splitter search inconsistent");
+        uint64_t need = rank[b] - less_total;  // elements equal to the boundary key that go below the cut
+        for (uint32_t g = 0; g < G; ++g) {      // ties: lower slice first (stability)
+            const uint64_t less = sh[g].c->shard_host[b], eq = sh[g].c->shard_host[nb + b] - less;
             const uint64_t take = need < eq ? need : eq;
-            split[g][b + 1] = less + take;
+            cut[b][g] = less + take;
             need -= take;
         }
         if (need != 0) return fail(ctx, RSX_ERR_INTERNAL, "splitter search inconsistent");
     }
+    return RSX_OK;
+}
+
+// split[g][h] .. split[g][h+1] of src[g] goes to owner h, behind the ranges of the slices before g
+int exchange(rsx_ctx* ctx, const std::vector<Shard>& sh, const std::vector<char*>& src, const std::vector<char*>& dst,
+             const std::vector<std::vector<uint64_t>>& split, size_t es) {
+    const uint32_t G = (uint32_t)sh.size();
     for (uint32_t h = 0; h < G; ++h) {
         uint64_t got = 0;
         for (uint32_t g = 0; g < G; ++g) {
             if (split[g][h + 1] < split[g][h]) return fail(ctx, RSX_ERR_INTERNAL, "splitters not monotone");
             got += split[g][h + 1] - split[g][h];
         }
-        if (got != n_per_dev[h]) return fail(ctx, RSX_ERR_INTERNAL, "exchange plan does not fill a slice");
+        if (got != sh[h].n) return fail(ctx, RSX_ERR_INTERNAL, "exchange plan does not fill a slice");
     }
-
-    // (3) the exchange: slice g pushes its range for owner h into h's scratch, behind the ranges
-    // of the slices before it.  d_tmps is idle (all local sorts were synchronised above).
     for (uint32_t g = 0; g < G; ++g) {
-        std::lock_guard<std::mutex> lk(ctxs[g]->mu);
-        DeviceGuard dg(ctxs[g]->device);
+        DeviceGuard dg(sh[g].c->device);
         for (uint32_t k = 0; k < G; ++k) {
             const uint32_t h = (g + k) % G;  // start with myself, then round the ring: spreads the links
             const uint64_t cnt = split[g][h + 1] - split[g][h];
             if (cnt == 0) continue;
             uint64_t at = 0;
             for (uint32_t p = 0; p < g; ++p) at += split[p][h + 1] - split[p][h];
-            const char* src = static_cast<const char*>(d_slices[g]) + split[g][h] * es;
-            char* dst = static_cast<char*>(d_tmps[h]) + at * es;
-            if (ctxs[h]->device == ctxs[g]->device) {
-                RSX_HIP(hipMemcpyAsync(dst, src, cnt * es, hipMemcpyDeviceToDevice, nullptr));
+            const char* s = src[g] + split[g][h] * es;
+            char* d = dst[h] + at * es;
+            if (sh[h].c->device == sh[g].c->device) {
+                RSX_HIP(hipMemcpyAsync(d, s, cnt * es, hipMemcpyDeviceToDevice, sh[g].c->shard_stream));
             } else {
-                // direct xGMI writes where the topology allows; the copy works either way
-                if (hipDeviceEnablePeerAccess(ctxs[h]->device, 0) != hipSuccess) (void)hipGetLastError();
-                RSX_HIP(hipMemcpyPeerAsync(dst, ctxs[h]->device, src, ctxs[g]->device, cnt * es, nullptr));
+                enable_peer(sh[g].c->device, sh[h].c->device);
+                RSX_HIP(hipMemcpyPeerAsync(d, sh[h].c->device, s, sh[g].c->device, cnt * es, sh[g].c->shard_stream));
             }
         }
     }
+    return sync_all(ctx, sh);
+}
+
+}  // namespace
+
+int rsx_sort_sharded_ex(rsx_ctx* const* ctxs, uint32_t ndev, void* const* d_slices, void* const* d_tmps,
+                        const size_t* n_per_dev, const rsx_layout* L, int schedule) try {
+    if (!ctxs || ndev == 0 || !ctxs[0]) return RSX_ERR_ARG;
+    rsx_ctx* ctx = ctxs[0];  // carries the error text
+    if (!d_slices || !d_tmps || !n_per_dev) return fail(ctx, RSX_ERR_ARG, "null table");
+    if (schedule != RSX_SHARD_EXCHANGE_FIRST && schedule != RSX_SHARD_SORT_FIRST) return fail(ctx, RSX_ERR_ARG, "unknown schedule");
+    const uint32_t G = ndev;
+    if (G > 64) return fail(ctx, RSX_ERR_ARG, "more than 64 slices");
+    std::vector<Shard> sh(G);
+    const uint32_t al = L ? elem_align(L->elem_bytes) : 1;
     for (uint32_t g = 0; g < G; ++g) {
-        DeviceGuard dg(ctxs[g]->device);
-        RSX_HIP(hipStreamSynchronize(nullptr));
+        if (!ctxs[g]) return fail(ctx, RSX_ERR_ARG, "null context in table");
+        int rc = check_common(ctxs[g], L);
+        if (rc) return rc == RSX_ERR_ARG ? fail(ctx, rc, "invalid rsx_layout") : fail(ctx, rc, "element size has no device kernel");
+        if (n_per_dev[g] && (!d_slices[g] || !d_tmps[g])) return fail(ctx, RSX_ERR_ARG, "null device pointer");
+        if (n_per_dev[g] && (!aligned(d_slices[g], al) || !aligned(d_tmps[g], al))) return fail(ctx, RSX_ERR_ARG, "device pointer misaligned");
+        for (uint32_t h = 0; h < g; ++h)
+            if (ctxs[h] == ctxs[g]) return fail(ctx, RSX_ERR_ARG, "one context per slice");
+        sh[g] = Shard{ctxs[g], static_cast<char*>(d_slices[g]), static_cast<char*>(d_tmps[g]), n_per_dev[g]};
     }
-    // (4) G sorted runs per slice -> one: a stable sort of the received slice
+    const size_t es = L->elem_bytes;
+    const uint32_t D = L->key_bytes;
     for (uint32_t g = 0; g < G; ++g) {
-        if (n_per_dev[g] == 0) continue;
-        DeviceGuard dg(ctxs[g]->device);
-        RSX_HIP(hipMemcpyAsync(d_slices[g], d_tmps[g], n_per_dev[g] * es, hipMemcpyDeviceToDevice, nullptr));
+        int rc = shard_prepare(ctx, ctxs[g]);
+        if (rc) return rc;
     }
+    std::vector<char*> slices(G), tmps(G);
+    for (uint32_t g = 0; g < G; ++g) {
+        slices[g] = sh[g].data;
+        tmps[g] = sh[g].tmp;
+    }
+    auto sort_all = [&]() -> int {
+        for (uint32_t g = 0; g < G; ++g) {
+            int rc = sort_async(ctx, sh[g].c, sh[g].data, sh[g].tmp, sh[g].n, L);
+            if (rc) return rc;
+        }
+        return sync_all(ctx, sh);
+    };
+    if (G == 1) return sort_all();
+
+    std::vector<uint64_t> bounds(G + 1, 0);
+    for (uint32_t g = 0; g < G; ++g) bounds[g + 1] = bounds[g] + sh[g].n;
+    const uint32_t nb = G - 1;
+    std::vector<std::vector<uint64_t>> split(G, std::vector<uint64_t>(G + 1, 0));
+    for (uint32_t g = 0; g < G; ++g) split[g][G] = sh[g].n;
+    std::vector<std::vector<uint64_t>> cut;
+
+    if (schedule == RSX_SHARD_SORT_FIRST) {
+        int rc = sort_all();
+        if (rc) return rc;
+        std::vector<std::vector<Range>> rng(nb, std::vector<Range>(G));
+        std::vector<uint64_t> rank(nb);
+        for (uint32_t b = 0; b < nb; ++b) {
+            rank[b] = bounds[b + 1];
+            for (uint32_t g = 0; g < G; ++g) rng[b][g] = Range{0, sh[g].n};
+        }
+        rc = find_cuts(ctx, sh, slices, L, rng, rank, (int)D - 1, std::vector<uint64_t>(nb, 0), std::vector<uint64_t>(nb, 0), cut);
+        if (rc) return rc;
+        for (uint32_t b = 0; b < nb; ++b)
+            for (uint32_t g = 0; g < G; ++g) split[g][b + 1] = cut[b][g];
+        rc = exchange(ctx, sh, slices, tmps, split, es);
+        if (rc) return rc;
+        for (uint32_t g = 0; g < G; ++g) {  // back into the slices (an even number of passes ends where it starts)
+            if (sh[g].n == 0) continue;
+            DeviceGuard dg(sh[g].c->device);
+            RSX_HIP(hipMemcpyAsync(sh[g].data, sh[g].tmp, sh[g].n * es, hipMemcpyDeviceToDevice, sh[g].c->shard_stream));
+        }
+        return sort_all();
+    }
+
+    // ---- exchange first ----
+    // (1) one stable partition pass by the most significant digit, slice -> tmp, with its 256 counts
+    const uint32_t top = D - 1;
+    for (uint32_t g = 0; g < G; ++g) {
+        rsx_ctx* c = sh[g].c;
+        std::lock_guard<std::mutex> lk(c->mu);
+        DeviceGuard dg(c->device);
+        uint64_t* hh = c->shard_host + (size_t)64 * RADIX * 2;  // pinned: this slice's 256 counts
+        if (sh[g].n == 0) {
+            std::memset(hh, 0, RADIX * sizeof(uint64_t));
+            continue;
+        }
+        int rc = partition_locked(c, sh[g].data, sh[g].tmp, sh[g].n, L, top, c->shard_hist, c->shard_stream);
+        if (rc) return c != ctx ? fail(ctx, rc, c->err.c_str()) : rc;
+        RSX_HIP(hipMemcpyAsync(hh, c->shard_hist, RADIX * sizeof(uint64_t), hipMemcpyDeviceToHost, c->shard_stream));
+    }
+    int rc = sync_all(ctx, sh);
+    if (rc) return rc;
+    // (2) global layout of the buckets; which boundaries fall inside one
+    std::vector<std::vector<uint64_t>> lstart(G, std::vector<uint64_t>(RADIX + 1, 0));
+    std::vector<uint64_t> gstart(RADIX + 1, 0);
+    for (uint32_t v = 0; v < RADIX; ++v) {
+        uint64_t tot = 0;
+        for (uint32_t g = 0; g < G; ++g) {
+            const uint64_t c = sh[g].c->shard_host[(size_t)64 * RADIX * 2 + v];
+            lstart[g][v + 1] = lstart[g][v] + c;
+            tot += c;
+        }
+        gstart[v + 1] = gstart[v] + tot;
+    }
+    for (uint32_t g = 0; g < G; ++g)
+        if (lstart[g][RADIX] != sh[g].n) return fail(ctx, RSX_ERR_INTERNAL, "digit counts do not add up to the slice");
+    std::vector<uint32_t> inside;       // boundaries that fall strictly inside a bucket
+    std::vector<uint32_t> bucket_of(nb, RADIX);
+    bool sorted_bucket[RADIX] = {false};
+    for (uint32_t b = 0; b < nb; ++b) {
+        const uint64_t T = bounds[b + 1];
+        uint32_t v = 0;
+        while (v < RADIX && gstart[v + 1] <= T) ++v;  // first bucket that ends above T
+        bucket_of[b] = v;
+        if (v == RADIX || gstart[v] == T) {
+            for (uint32_t g = 0; g < G; ++g) split[g][b + 1] = v == RADIX ? sh[g].n : lstart[g][v];
+            continue;
+        }
+        inside.push_back(b);
+        if (!sorted_bucket[v]) {  // every device sorts its piece of this bucket: tmp piece in place, slice piece as scratch
+            sorted_bucket[v] = true;
+            for (uint32_t g = 0; g < G; ++g) {
+                const uint64_t off = lstart[g][v] * es;
+                rc = sort_async(ctx, sh[g].c, sh[g].tmp + off, sh[g].data + off, lstart[g][v + 1] - lstart[g][v], L);
+                if (rc) return rc;
+            }
+        }
+    }
+    if (!inside.empty()) {
+        rc = sync_all(ctx, sh);
+        if (rc) return rc;
+        const uint32_t ni = (uint32_t)inside.size();
+        std::vector<std::vector<Range>> rng(ni, std::vector<Range>(G));
+        std::vector<uint64_t> rank(ni), pre_lo(ni, 0), pre_hi(ni, 0);
+        for (uint32_t i = 0; i < ni; ++i) {
+            const uint32_t b = inside[i], v = bucket_of[b];
+            rank[i] = bounds[b + 1] - gstart[v];
+            if (top < 8) pre_lo[i] = (uint64_t)v << (8 * top);
+            else pre_hi[i] = (uint64_t)v << (8 * (top - 8));
+            for (uint32_t g = 0; g < G; ++g) rng[i][g] = Range{lstart[g][v], lstart[g][v + 1]};
+        }
+        rc = find_cuts(ctx, sh, tmps, L, rng, rank, (int)top - 1, pre_lo, pre_hi, cut);
+        if (rc) return rc;
+        for (uint32_t i = 0; i < ni; ++i)
+            for (uint32_t g = 0; g < G; ++g) split[g][inside[i] + 1] = lstart[g][bucket_of[inside[i]]] + cut[i][g];
+    }
+    // (3) the exchange, straight into the slices (their old contents live on in the tmps); (4) one local sort
+    rc = exchange(ctx, sh, tmps, slices, split, es);
+    if (rc) return rc;
     return sort_all();
 } catch (...) {
     return RSX_ERR_NOMEM;
+}
+
+int rsx_sort_sharded(rsx_ctx* const* ctxs, uint32_t ndev, void* const* d_slices, void* const* d_tmps,
+                     const size_t* n_per_dev, const rsx_layout* L) {
+    return rsx_sort_sharded_ex(ctxs, ndev, d_slices, d_tmps, n_per_dev, L, RSX_SHARD_EXCHANGE_FIRST);
 }
 
 int rsx_generate_device(rsx_ctx* ctx, void* d_data, size_t n, const rsx_layout* L, int gen, uint64_t seed,
@@ -987,8 +1051,23 @@ int rsx_generate_device(rsx_ctx* ctx, void* d_data, size_t n, const rsx_layout* 
     if (!layout_ok(L)) return fail(ctx, RSX_ERR_ARG, "invalid rsx_layout");
     if (n == 0) return RSX_OK;
     if (!d_data) return fail(ctx, RSX_ERR_ARG, "null pointer");
-    if (gen < RSX_GEN_UNIFORM || gen > RSX_GEN_CONSTANT) return fail(ctx, RSX_ERR_ARG, "unknown generator");
-    if (gen == RSX_GEN_STEP && !(param >= 1.0)) return fail(ctx, RSX_ERR_ARG, "step generator needs param >= 1");
+    const uint32_t payload_zero = (gen & RSX_GEN_PAYLOAD_ZERO) ? 1u : 0u;
+    gen &= ~RSX_GEN_PAYLOAD_ZERO;
+    if (gen < RSX_GEN_UNIFORM || gen > RSX_GEN_GEOMETRIC) return fail(ctx, RSX_ERR_ARG, "unknown generator");
+    uint64_t iparam = 0;
+    if (gen == RSX_GEN_STEP) {
+        if (!(param >= 1.0)) return fail(ctx, RSX_ERR_ARG, "step generator needs param >= 1");
+        iparam = (uint64_t)param;
+    } else if (gen == RSX_GEN_CONSTANT) {
+        iparam = (uint64_t)param;
+    } else if (gen == RSX_GEN_GEOMETRIC) {
+        if (!(param > 0.0 && param < 1.0)) return fail(ctx, RSX_ERR_ARG, "geometric generator needs 0 < param < 1");
+        // -log2(1 - p) as 32.32 fixed point (made on the host, once: the kernel divides by it)
+        const double c = -std::log2(1.0 - param) * 4294967296.0;
+        iparam = c < 1.0 ? 1ull : c >= 18446744073709551615.0 ? ~0ull : (uint64_t)c;
+    } else if (gen == RSX_GEN_ZIPF) {
+        if (!(param > 0.0)) return fail(ctx, RSX_ERR_ARG, "Zipf generator needs param > 0");
+    }
     std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard g(ctx->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -996,7 +1075,8 @@ int rsx_generate_device(rsx_ctx* ctx, void* d_data, size_t n, const rsx_layout* 
     const uint64_t cap = (uint64_t)ctx->num_cu * 16;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(rsx_generate_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, static_cast<uint8_t*>(d_data),
-                       (uint64_t)n, L->elem_bytes, L->key_offset, L->key_bytes, gen, seed, param, index_base);
+                       (uint64_t)n, L->elem_bytes, L->key_offset, L->key_bytes, gen, seed, param, iparam, index_base,
+                       payload_zero);
     RSX_HIP(hipGetLastError());
     return RSX_OK;
 } catch (...) {

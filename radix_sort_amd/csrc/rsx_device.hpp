@@ -4,9 +4,10 @@
 // (src/radix_sort/mod.rs:84-169) with:
 //   rsx_hist_kernel    count phase (mod.rs:90-109) of the first pass: digit counts per
 //                      region (region == the reference's chunk)
-//   rsx_prefix_kernel  prefix phase (mod.rs:110-120): digit-major, region-minor
-//                      exclusive scan of the count matrix -> write cursors
-//   rsx_sweep_kernel   scatter phase (mod.rs:121-168) of one pass: tile-local stable
+//   rsx_sweep_kernel   prefix phase (mod.rs:110-120) in its prologue: every workgroup takes the
+//                      digit-major, region-minor exclusive scan of the count matrix for the
+//                      region it serves; then the
+//                      scatter phase (mod.rs:121-168) of one pass: tile-local stable
 //                      ranking with wave64 ballots, decoupled look-back inside each
 //                      region's chain of tiles, LDS reorder, coalesced run writes;
 //                      counts the NEXT pass's digit per destination region on the way
@@ -239,6 +240,9 @@ struct RegionGeom {
 };
 
 // --------------------------------------------------------------- histogram --
+#ifndef RSX_HIST_UNROLL
+#define RSX_HIST_UNROLL 1  // more loads in flight per thread measured slower (0.217 -> 0.228 ms per 2^28 u32 at 4)
+#endif
 // Count phase for ONE digit with chunk == region: J[r][v] for the pass's input.
 // grid = num_regions * blocks_per_region; a block stays inside one region.
 // (Only the first pass of a sort needs this kernel: each sweep pass counts the
@@ -275,10 +279,18 @@ __global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restric
     const uint64_t nvec = (end - begin) / VEC;
     const Pack* vsrc = reinterpret_cast<const Pack*>(src + begin);
     const uint64_t stride = (uint64_t)blocks_per_region * blockDim.x;
-    for (uint64_t i = (uint64_t)sub * blockDim.x + tid; i < nvec; i += stride) {
-        const Pack p = vsrc[i];
+    constexpr int UNR = RSX_HIST_UNROLL;
+    for (uint64_t i = (uint64_t)sub * blockDim.x + tid; i < nvec; i += stride * UNR) {
+        Pack p[UNR];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) count(p.e[k]);
+        for (int u = 0; u < UNR; ++u)
+            if (i + u * stride < nvec) p[u] = vsrc[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            if (i + u * stride < nvec) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) count(p[u].e[k]);
+            }
     }
     if (VEC > 1 && sub == 0) {  // tail of the region (fewer than VEC elements)
         const uint64_t i = begin + nvec * VEC + tid;
@@ -289,41 +301,6 @@ __global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restric
         const uint32_t c = lh[tid];
         if (c) atomicAdd(&J[r * RADIX + tid], (unsigned long long)c);
     }
-}
-
-// Prefix phase (mod.rs:110-120): from J[r][v] to the write cursor of every (region,
-// digit): base[r][v] = sum_{v' < v} sum_r' J[r'][v'] + sum_{r' < r} J[r'][v] -- the
-// digit-major, region-minor exclusive running sum.  One block of 256 threads.
-// Also clears what the coming sweep accumulates into (next J, region tickets) and
-// optionally returns the 256 digit totals.
-__global__ __launch_bounds__(256) void rsx_prefix_kernel(const unsigned long long* __restrict__ J,
-                                                         uint32_t num_regions, uint64_t* __restrict__ base,
-                                                         unsigned long long* __restrict__ jnext,
-                                                         uint32_t* __restrict__ tickets,
-                                                         uint64_t* __restrict__ counts_out) {
-    __shared__ uint64_t wsum[4];
-    const uint32_t tid = threadIdx.x;
-    uint64_t c = 0;
-    for (uint32_t r = 0; r < num_regions; ++r) c += J[r * RADIX + tid];
-    if (counts_out) counts_out[tid] = c;
-    uint64_t x = c;
-    const uint32_t lane = tid & 63;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint64_t y = __shfl_up(x, o);
-        if (lane >= (uint32_t)o) x += y;
-    }
-    if (lane == 63) wsum[tid >> 6] = x;
-    __syncthreads();
-    uint64_t run = x - c;
-    for (uint32_t w = 0; w < (tid >> 6); ++w) run += wsum[w];
-    for (uint32_t r = 0; r < num_regions; ++r) {
-        base[r * RADIX + tid] = run;
-        run += J[r * RADIX + tid];
-    }
-    if (jnext)
-        for (uint32_t r = 0; r < MAX_REGIONS; ++r) jnext[r * RADIX + tid] = 0;
-    if (tid < MAX_REGIONS + 2) tickets[tid] = 0;  // + roll-call words of the sweep
 }
 
 // -------------------------------------------------------------------- sweep --
@@ -348,10 +325,13 @@ struct SweepArgs {
     const void* src;
     void* dst;
     RegionGeom g;
-    const uint64_t* region_base;  // [num_regions][256] write cursor (elements) at region start
+    const unsigned long long* J;  // [num_regions][256] this pass's count matrix (count phase, mod.rs:90-109): every
+                                  // workgroup derives its region's write cursors from it (prefix phase, mod.rs:110-120)
     void* status;                 // [num_regions << (region_shift - log2 TILE)][256], zeroed
-    uint32_t* tickets;            // [MAX_REGIONS] per-region tile counters, zeroed; [MAX_REGIONS], [MAX_REGIONS+1]:
-                                  // arrival count and mode word of the start-up roll call, zeroed
+    uint32_t* tickets;            // this pass's words, zeroed: [MAX_REGIONS] per-region tile counters; [MAX_REGIONS],
+                                  // [MAX_REGIONS+1]: arrival count and mode word of the start-up roll call
+    const uint32_t* prev_mode;    // the previous pass's mode word (null on a first pass): a roll call that failed
+                                  // there is not waited for again here
     uint16_t wg_first[MAX_REGIONS + 1];  // static mode: region r is served by workgroups [wg_first[r], wg_first[r+1])
     void* status_clean;           // the next pass's status words: every tile zeroes its row there (null on a last pass)
     uint32_t rank_atomic;         // 1: ranks may come from returned LDS atomics (ordering self-test passed)
@@ -359,13 +339,23 @@ struct SweepArgs {
     uint32_t tiles_per_region;    // ceil(region length / tile): status rows per region
     uint32_t local_mask;          // static mode: regions whose workgroups all sit in one residue class of blockIdx % 8
     unsigned long long* jnext;    // [MAX_REGIONS][256] next pass's count matrix (accumulated), or null
-    uint32_t* error;              // set non-zero if a bounded spin gave up
+    unsigned long long* jzero;    // [MAX_REGIONS][256] count matrix of the pass after next: cleared here, or null
+    uint32_t* error;              // host-visible (pinned) word: set non-zero if a bounded spin gave up
     DigitSpec spec;               // this pass's digit
     DigitSpec next;               // next pass's digit (when jnext != null)
     KeyXform xf;                  // signed/float key map applied on load (XF & 1) / undone on store (XF & 2)
-    uint32_t dbg;                 // timing-only ablation switches (0 in production)
-    unsigned long long* dbg_cnt;  // [8] diagnostic counters (dbg & 0x100)
+    uint32_t opts;                // alternative paths, all bit-exact: SWEEP_OPT_*
+    uint32_t dbg;                 // RSX_TUNING builds: timing-only ablation switches (0 in production)
+    unsigned long long* dbg_cnt;  // [8] diagnostic counters (RSX_TUNING, dbg & 0x100)
 };
+constexpr uint32_t SWEEP_OPT_DYNAMIC = 1u;       // ticketed tiles, no roll call
+constexpr uint32_t SWEEP_OPT_NO_XCD_MAJOR = 2u;  // workgroups numbered by plain blockIdx
+constexpr uint32_t SWEEP_OPT_AGENT_STATUS = 4u;  // agent-scope status stores on every chain
+#ifdef RSX_TUNING
+#define RSX_DBG(a, bit) ((a).dbg & (bit))
+#else
+#define RSX_DBG(a, bit) 0u
+#endif
 
 // Persistent workgroups pull tiles region by region (rotating, so consecutive tiles of
 // one chain start far apart in time).  Tile = WG threads x KPT elements, held
@@ -419,6 +409,9 @@ struct SweepArgs {
 #endif
 #ifndef RSX_DPP_SCAN
 #define RSX_DPP_SCAN 2  // 0 off, 1 on, 2 = where measured faster (elements of <= 4 bytes)
+#endif
+#ifndef RSX_ROLLCALL_TICKS
+#define RSX_ROLLCALL_TICKS 40000  // s_memtime ticks (shader cycles) a workgroup waits for the full grid
 #endif
 #ifndef RSX_PREFETCH_ALL
 #define RSX_PREFETCH_ALL 3  // 0 off, 1 before/after the look-back, 2 behind it, 3 = 2 where measured faster (>= 12-byte elements)
@@ -509,7 +502,7 @@ template <int ES, int KPT, int WG, typename S, int XF, bool NEXT>
 // (measured: 0.82 -> 0.68 ms per 256M-key pass at 2 workgroups/CU without spills).
 // SGPR budget: the hardware admits waves by SGPRs too (800 per SIMD in blocks of 16, +16 per wave):
 // above 80 SGPRs a kernel cannot have 8 waves per SIMD however few VGPRs it uses.
-__global__ __launch_bounds__(WG, (WG == 1024 ? RSX_MINW_1024 : KPT * (ES < 4 ? 4 : ES) >= 64 ? RSX_MINW_BIG : RSX_MINW))
+__global__ __launch_bounds__(WG, (WG == 1024 ? RSX_MINW_1024 : ES == 16 ? 6 : KPT * (ES < 4 ? 4 : ES) >= 64 ? RSX_MINW_BIG : RSX_MINW))
 __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const SweepArgs a) {
     constexpr int NWAVE = WG / WAVE;
     constexpr int TILE = WG * KPT;
@@ -532,7 +525,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
     Cnt* s_whist = reinterpret_cast<Cnt*>(s_whist2);                                   // [NWAVE][256]
     uint64_t* s_base = reinterpret_cast<uint64_t*>(s_whist2);                          // [256], aliases s_whist (dead by then)
     uint32_t* s_jn = s_whist2 + NWAVE * RADIX * sizeof(Cnt) / 4;                       // [num_regions][256] (NEXT)
-    uint32_t* s_misc = s_jn + (NEXT ? a.g.num_regions * RADIX : 0);                    // [16]
+    uint32_t* s_misc = s_jn + (NEXT ? a.g.num_regions * RADIX : 0);                    // [32]
     static_assert(NWAVE * RADIX * sizeof(Cnt) >= RADIX * sizeof(uint64_t), "s_base must fit in s_whist");
 
     const E* __restrict__ src = static_cast<const E*>(a.src);
@@ -543,7 +536,30 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
 
     if (NEXT)
         for (uint32_t i = threadIdx.x; i < a.g.num_regions * RADIX; i += WG) s_jn[i] = 0;
+    // the count matrix of the pass after next is cleared here: its last readers (the previous pass)
+    // are done, its next writers (the next pass) have not started
+    if (a.jzero != nullptr)
+        for (uint32_t i = blockIdx.x * WG + threadIdx.x; i < (uint32_t)(MAX_REGIONS * RADIX); i += gridDim.x * WG) a.jzero[i] = 0;
 
+    // workgroup index, XCD-major (blocks are dealt round-robin over the 8 XCDs): the workgroups of
+    // one chain then share an XCD, which makes their status hand-offs faster -- never a
+    // correctness matter
+    const uint32_t bx = (gridDim.x % 8u == 0u && !(a.opts & SWEEP_OPT_NO_XCD_MAJOR)) ? (blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u : blockIdx.x;
+    uint32_t home = 0;
+    while (home + 1 < NR && bx >= a.wg_first[home + 1]) ++home;
+    const uint32_t st_step = a.wg_first[home + 1] - a.wg_first[home];  // M: workgroups serving my region
+    uint32_t st_k = bx - a.wg_first[home];                             // my next tile in static mode
+    uint32_t st_nt;
+    {
+        const uint64_t rbeg = (uint64_t)home << a.g.region_shift;
+        const uint64_t rlen = (a.g.n - rbeg) < region_len ? (a.g.n - rbeg) : region_len;
+        st_nt = (uint32_t)((rlen + TILE - 1) / TILE);
+    }
+    // (The first tile's loads are NOT issued ahead of the roll call: memory operations return in order,
+    // so the roll call's polls would queue behind 28 HBM loads per lane and time out -- measured: the
+    // grid then fell back to ticketed tiles, 0.46 -> 0.58 ms per 256M-key pass.)
+    E e[KPT];
+    bool preloaded = false;  // static mode: this tile's loads were issued during the previous tile
     // ---- who sorts which tile ----------------------------------------------------------
     // Tiles of a region form a chain and must START in order (a tile only waits for lower tiles
     // of its chain).  Two ways to guarantee that:
@@ -556,12 +572,18 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
     //    to see the full count (or to time out) fixes the mode for everybody with one CAS.
     //    A full count proves all workgroups are running, and a running workgroup stays
     //    resident until it exits.
+    //    The bound: s_memtime counts shader cycles on gfx950 (~2.1-2.4 GHz), a fully resident grid
+    //    answers within a few microseconds (a 1024-block grid starts first to last within 0.7 us),
+    //    so 40000 ticks (~18 us, ~4 % of a 256M-key pass) is ample; a grid that is not co-resident
+    //    (two streams, a co-tenant) costs that once per sort: the verdict carries over to the
+    //    later passes through prev_mode.
     if (threadIdx.x == 0) {
         uint32_t mode = 2;
-        if (!(a.dbg & 0x2000u)) {
+        if (!(a.opts & SWEEP_OPT_DYNAMIC) &&
+            !(a.prev_mode != nullptr && __hip_atomic_load(a.prev_mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2u)) {
             uint32_t* arrive = a.tickets + MAX_REGIONS;
             uint32_t* modew = a.tickets + MAX_REGIONS + 1;
-            // The same word also collects whether workgroups sit where the XCD-major numbering below
+            // The same word also collects whether workgroups sit where the XCD-major numbering
             // assumes (XCC id == blockIdx % 8): low half = arrivals, high half = workgroups that do not.
             uint32_t xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -573,42 +595,66 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                 seen = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((seen & 0xFFFFu) == gridDim.x) break;
                 __builtin_amdgcn_s_sleep(4);
-            } while (__builtin_amdgcn_s_memtime() - t0 < 200000ull);
+            } while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)RSX_ROLLCALL_TICKS);
             uint32_t expected = 0;
             const uint32_t verdict = (seen & 0xFFFFu) != gridDim.x ? 2u : (seen == gridDim.x ? 3u : 1u);
             __hip_atomic_compare_exchange_strong(modew, &expected, verdict, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                  __HIP_MEMORY_SCOPE_AGENT);
             mode = __hip_atomic_load(modew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (!(a.opts & SWEEP_OPT_DYNAMIC)) {
+            // carried-over failure: record it for the pass after this one as well
+            __hip_atomic_store(a.tickets + MAX_REGIONS + 1, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         s_misc[3] = mode;
     }
     __syncthreads();
     const uint32_t mode = __builtin_amdgcn_readfirstlane(s_misc[3]);  // 1/3 static, 2 dynamic, 3 = placement verified
     const bool static_mode = mode != 2u;
-    if ((a.dbg & 0x100u) && threadIdx.x == 0 && blockIdx.x == 0) {
+    if (RSX_DBG(a, 0x100u) && threadIdx.x == 0 && blockIdx.x == 0) {
         atomicAdd(&a.dbg_cnt[5], static_mode ? 1ull : 0ull);
         atomicAdd(&a.dbg_cnt[6], mode == 3u ? 1ull : 0ull);
     }
-    // workgroup index, XCD-major (blocks are dealt round-robin over the 8 XCDs): the workgroups of
-    // one chain then share an XCD, which makes their status hand-offs faster -- never a
-    // correctness matter
-    const uint32_t bx = (gridDim.x % 8u == 0u && !(a.dbg & 0x4000u)) ? (blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u : blockIdx.x;
-    uint32_t home = 0;
-    while (home + 1 < NR && bx >= a.wg_first[home + 1]) ++home;
-    const uint32_t st_step = a.wg_first[home + 1] - a.wg_first[home];  // M: workgroups serving my region
-    uint32_t st_k = bx - a.wg_first[home];                             // my next tile in static mode
-    uint32_t st_nt;
-    {
-        const uint64_t rbeg = (uint64_t)home << a.g.region_shift;
-        const uint64_t rlen = (a.g.n - rbeg) < region_len ? (a.g.n - rbeg) : region_len;
-        st_nt = (uint32_t)((rlen + TILE - 1) / TILE);
-    }
+    // ---- prefix phase (mod.rs:110-120) -------------------------------------------------
+    // Write cursor of (region r, digit v) at the region's start: the digit-major, region-minor
+    // exclusive running sum of the count matrix,
+    //     sum_{v' < v} sum_r' J[r'][v']  +  sum_{r' < r} J[r'][v].
+    // Every workgroup derives the 256 cursors of the region it serves itself (<= 16 x 256 counts,
+    // L2-resident); thread v keeps digit v's cursor in registers for all its tiles.
+    uint64_t rbase = 0;
+    uint64_t* s_scan = reinterpret_cast<uint64_t*>(s_misc + 16);  // [4]
+    auto region_cursors = [&](uint32_t r) {  // every thread calls (barriers inside); r is wave-uniform
+        const uint32_t t = threadIdx.x;
+        uint64_t tot = 0, below = 0;
+        if (t < RADIX) {
+            for (uint32_t q = 0; q < NR; ++q) {
+                const uint64_t c = a.J[q * RADIX + t];
+                tot += c;
+                below += q < r ? c : 0ull;
+            }
+        }
+        uint64_t x = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint64_t y = __shfl_up(x, o);
+            if ((t & 63u) >= (uint32_t)o) x += y;
+        }
+        if (t < RADIX && (t & 63u) == 63u) s_scan[t >> 6] = x;
+        __syncthreads();
+        if (t < RADIX) {
+            uint64_t run = x - tot + below;
+            for (uint32_t w = 0; w < (t >> 6); ++w) run += s_scan[w];
+            rbase = run;
+        }
+        __syncthreads();
+    };
+    uint32_t cur_reg = home;
+    region_cursors(home);
     // A chain whose workgroups were all verified on ONE XCD shares one L2: its status words can then
     // be plain stores that stay in that L2 (an agent-scope store writes through to memory and the
     // next agent-scope load of the line misses: 750 vs 510 cycles per hand-off, tools/microbench/pingpong.hip).
     // The loads stay agent-scope (they bypass the reader's L1 and hit the L2).  Speed only: without
     // the proof every status store is agent-scope.
-    const bool local_chain = mode == 3u && ((a.local_mask >> home) & 1u) != 0u && !(a.dbg & 0x8000u);
+    const bool local_chain = mode == 3u && ((a.local_mask >> home) & 1u) != 0u && !(a.opts & SWEEP_OPT_AGENT_STATUS);
     auto publish = [&](S* p, S v) {
         if (local_chain) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -645,8 +691,6 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
 #endif
-    E e[KPT];
-    bool preloaded = false;  // static mode: this tile's loads were issued during the previous tile
     while (true) {
         // thread coordinates are re-derived per tile from an opaque copy of threadIdx: otherwise
         // every tid-derived address (dozens of VGPRs) is hoisted out of this loop and spilled
@@ -678,6 +722,10 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
             if (__builtin_amdgcn_readfirstlane(s_misc[0]) == 0) break;
             reg = __builtin_amdgcn_readfirstlane(s_misc[1]);
             kt = __builtin_amdgcn_readfirstlane(s_misc[2]);
+            if (reg != cur_reg) {  // wave-uniform: this workgroup moved on to another region's chain
+                region_cursors(reg);
+                cur_reg = reg;
+            }
         }
 
         const uint64_t tile_base = ((uint64_t)reg << a.g.region_shift) + (uint64_t)kt * TILE;
@@ -840,7 +888,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         RSX_STAMP(2);
         // from here to the end of the tile the workgroup is on short, serial phases that every
         // wave waits for: let them win issue arbitration over other workgroups' match phases
-        if (!(a.dbg & 0x1000u)) __builtin_amdgcn_s_setprio(2);
+        if (!RSX_DBG(a, 0x1000u)) __builtin_amdgcn_s_setprio(2);
 
         // ---- per-digit: wave counts -> tile count, publish aggregate --------------
         uint32_t tcount = 0;
@@ -953,13 +1001,13 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                     left -= used;
                     if (used == 0) {
                         if (++spins > (1u << 22)) {  // bounded: never hang the device
-                            atomicExch(a.error, 1u);
+                            __hip_atomic_store(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                             break;
                         }
                         __builtin_amdgcn_s_sleep(1);
                     }
                 }
-                if ((a.dbg & 0x100u) && tid == 0) {  // diagnostics: hop / stall statistics of digit 0
+                if (RSX_DBG(a, 0x100u) && tid == 0) {  // diagnostics: hop / stall statistics of digit 0
                     atomicAdd(&a.dbg_cnt[0], 1ull);
                     atomicAdd(&a.dbg_cnt[1], (unsigned long long)hops);
                     atomicAdd(&a.dbg_cnt[2], (unsigned long long)spins);
@@ -969,7 +1017,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                 publish(&status[stat_row + tid], ((S)2 << Status<S>::SHIFT) | (S)((excl + real) & (uint64_t)Status<S>::MASK));
             }
             // element index of LDS slot 0 if it belonged to this digit's run (wrap-safe in u64)
-            s_base[tid] = a.region_base[reg * RADIX + tid] + excl - (uint64_t)tstart;
+            s_base[tid] = rbase + excl - (uint64_t)tstart;
             if (prefetch && RSX_PREFETCH_ALL == 1) issue_next();
         }
         __syncthreads();
@@ -978,7 +1026,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
 
         // ---- write runs: consecutive threads -> consecutive addresses within a run;
         // ---- count the NEXT pass's digit per destination region on the way out
-        if (!(a.dbg & 2u)) {
+        if (!RSX_DBG(a, 2u)) {
             E* __restrict__ dst = static_cast<E*>(a.dst);
             // physical LDS slot of logical slot i*WG + tid (see the swizzle at the reorder): only the low
             // five bits change, by (i*WG/32 + tid/32) & 31 -- two values per thread when WG % 512 == 0
@@ -1012,7 +1060,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                         }
                         if constexpr (NEXT) {
                             if constexpr (CROWD) count_next(s_jn, next_bin(idx, x));
-                            else atomicAdd(&s_jn[next_bin(idx, x)], 1u);
+                            else if (!RSX_DBG(a, 0x8u)) atomicAdd(&s_jn[next_bin(idx, x)], 1u);  // (0x8: ablation, no next-pass count)
                         }
                         // (element by element on purpose: issuing a group's LDS reads ahead of its atomics was
                         // measured no faster on u32 and slower on 8/16-byte elements)
@@ -1065,55 +1113,6 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
     }
 }
 
-// ------------------------------------------------------------ one-byte elements --
-// An element that IS its one-byte key (u8, i8) is fully described by its digit: the sorted array is
-// the 256 counts written out as runs (counting sort: one read of the data, one write, no scatter).
-// `counts` are by mapped digit (the count kernel maps signed keys); byte = mapped value ^ xor_mask.
-__global__ __launch_bounds__(256) void rsx_expand_bytes_kernel(uint8_t* __restrict__ dst, uint64_t n,
-                                                               const uint64_t* __restrict__ counts,
-                                                               uint32_t xor_mask) {
-    __shared__ uint64_t start[RADIX + 1];
-    __shared__ uint64_t wsum[4];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint64_t x = counts[tid];
-    const uint64_t c = x;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint64_t y = __shfl_up(x, o);
-        if (lane >= (uint32_t)o) x += y;
-    }
-    if (lane == 63) wsum[wave] = x;
-    __syncthreads();
-    uint64_t wb = 0;
-    for (uint32_t w = 0; w < wave; ++w) wb += wsum[w];
-    start[tid] = wb + x - c;
-    if (tid == RADIX - 1) start[RADIX] = wb + x;
-    __syncthreads();
-    const bool wide = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;  // 16-byte stores need the alignment
-    const uint64_t chunks = (n + 15) / 16;
-    for (uint64_t ch = (uint64_t)blockIdx.x * blockDim.x + tid; ch < chunks; ch += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t p0 = ch * 16;
-        uint32_t lo = 0, hi = RADIX;  // last v with start[v] <= p0
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) / 2;
-            if (start[mid] <= p0) lo = mid;
-            else hi = mid;
-        }
-        uint32_t v = lo;
-        uint32_t w[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            while (v < RADIX - 1 && start[v + 1] <= p0 + k) ++v;  // empty digits are stepped over
-            w[k / 4] |= ((v ^ xor_mask) & 0xFFu) << (8 * (k % 4));
-        }
-        if (wide && p0 + 16 <= n) {
-            *reinterpret_cast<uint4*>(dst + p0) = make_uint4(w[0], w[1], w[2], w[3]);
-        } else {
-            for (int k = 0; k < 16 && p0 + k < n; ++k) dst[p0 + k] = (uint8_t)(w[k / 4] >> (8 * (k % 4)));
-        }
-    }
-}
-
 // ------------------------------------------------------------ segmented copy --
 // One workgroup walks segments grid-stride; segment copy is element-granular.
 template <int ES>
@@ -1130,218 +1129,6 @@ __global__ __launch_bounds__(256) void rsx_segcopy_kernel(const Elem<ES>* __rest
     const uint64_t so = src_off[seg], dof = dst_off[seg];
     for (uint64_t i = (uint64_t)sub * blockDim.x + threadIdx.x; i < L; i += (uint64_t)blocks_per_seg * blockDim.x)
         dst[dof + i] = src[so + i];
-}
-
-// ------------------------------------------------------------------ harness --
-__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-}
-__device__ __forceinline__ uint64_t rand64(uint64_t seed, uint64_t index) {
-    return splitmix64(seed + index * 0x9E3779B97F4A7C15ull);
-}
-
-// ------------------------------------------------------------- LDS atomic order --
-// Self-test behind a.rank_atomic: when several lanes of ONE ds_add_rtn instruction hit the same
-// address, the sweep needs them applied in ascending lane order (then the returned values are
-// stable ranks).  The ISA documents no order, so it is established on the device at hand: 64
-// address patterns (1..256 distinct addresses; hashed, lane-cyclic, blocked and same-bank layouts;
-// both the 32-bit and the packed 16-bit counter forms), every lane checks its two returned values
-// against the ballot-derived rank.  Any mismatch sets *fail and the sweep keeps to ballots.
-__global__ __launch_bounds__(512) void rsx_lds_order_kernel(uint32_t* __restrict__ fail) {
-    __shared__ uint32_t cnt[8][RADIX];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    static constexpr uint32_t BINS[8] = {1, 2, 3, 5, 16, 64, 256, 256};
-    uint32_t bad = 0;
-    for (uint32_t p = 0; p < 64; ++p) {
-        for (uint32_t i = lane; i < RADIX; i += WAVE) cnt[wave][i] = 0;  // LDS serves one wave in order
-        const uint32_t bins = BINS[p & 7];
-        const uint32_t h = (uint32_t)(splitmix64(((uint64_t)blockIdx.x << 32) ^ (p << 16) ^ (wave << 8) ^ lane) >> 32);
-        uint32_t d;
-        switch ((p >> 3) & 3) {
-            case 0: d = h % bins; break;                        // hashed
-            case 1: d = lane % bins; break;                     // cyclic: neighbours differ
-            case 2: d = (lane * bins) / WAVE; break;            // blocked: neighbours share
-            default: d = ((h % bins) * 32u) % RADIX; break;     // distinct addresses in one bank
-        }
-        const uint64_t m = match_digit<8>(d);
-        const uint32_t below = mbcnt64(m), group = (uint32_t)__popcll(m);
-        uint32_t r1, r2;
-        if (p & 32) {  // packed: two 16-bit counters per word
-            const uint32_t sh = (d & 1u) * 16u;
-            r1 = (atomicAdd(&cnt[wave][d >> 1], 1u << sh) >> sh) & 0xFFFFu;
-            r2 = (atomicAdd(&cnt[wave][d >> 1], 1u << sh) >> sh) & 0xFFFFu;
-        } else {
-            r1 = atomicAdd(&cnt[wave][d], 1u);
-            r2 = atomicAdd(&cnt[wave][d], 1u);
-        }
-        if (r1 != below || r2 != group + below) bad = 1;
-    }
-    if (__ballot(bad != 0) != 0 && lane == 0) atomicOr(fail, 1u);
-}
-
-// key (as up to 128 bits lo/hi) for generator `gen`
-__device__ __forceinline__ void gen_key(int gen, uint64_t seed, double param, uint64_t gi, uint64_t n_total,
-                                        uint32_t key_bytes, uint64_t& lo, uint64_t& hi) {
-    const uint32_t bits = key_bytes * 8;
-    lo = hi = 0;
-    switch (gen) {
-        case 0:  // uniform
-            lo = rand64(seed, gi);
-            hi = rand64(seed ^ 0xA5A5A5A5A5A5A5A5ull, gi);
-            break;
-        case 1: {  // Zipf-shaped: continuous inverse of H(x) = (x^(1-s) - 1)/(1-s), N = 2^min(bits,64) - 1
-            const double u = (double)(rand64(seed, gi) >> 11) * (1.0 / 9007199254740992.0);
-            const double N1 = bits >= 64 ? 18446744073709551616.0 : (double)(1ull << bits);
-            double x;
-            if (param == 1.0) x = exp(u * log(N1));
-            else x = pow(1.0 + u * (pow(N1, 1.0 - param) - 1.0), 1.0 / (1.0 - param));
-            x = floor(x) - 1.0;
-            if (x < 0) x = 0;
-            lo = x >= 18446744073709551615.0 ? ~0ull : (uint64_t)x;
-            break;
-        }
-        case 2: {  // step-uniform over `param` equally spaced values (distr.rs:78-106)
-            const uint64_t k = (uint64_t)param;
-            const uint64_t maxv = bits >= 64 ? ~0ull : ((1ull << bits) - 1);
-            const uint64_t s = maxv / (k + 1);
-            lo = s * (1 + rand64(seed, gi) % k);
-            break;
-        }
-        case 3: lo = gi; break;
-        case 4: lo = n_total - 1 - gi; break;
-        default: lo = (uint64_t)param; break;
-    }
-}
-
-__global__ __launch_bounds__(256) void rsx_generate_kernel(uint8_t* __restrict__ data, uint64_t n,
-                                                           uint32_t elem_bytes, uint32_t key_offset,
-                                                           uint32_t key_bytes, int gen, uint64_t seed, double param,
-                                                           uint64_t index_base) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint64_t gi = index_base + i;
-        uint64_t lo, hi;
-        gen_key(gen, seed, param, gi, index_base + n, key_bytes, lo, hi);
-        uint8_t* e = data + i * elem_bytes;
-        uint32_t pb = 0;  // payload byte counter
-        for (uint32_t b = 0; b < elem_bytes; ++b) {
-            if (b >= key_offset && b < key_offset + key_bytes) {
-                const uint32_t kb = b - key_offset;
-                e[b] = (uint8_t)((kb < 8 ? lo >> (8 * kb) : hi >> (8 * (kb - 8))) & 0xFF);
-            } else {
-                e[b] = pb < 8 ? (uint8_t)((gi >> (8 * pb)) & 0xFF) : 0;
-                ++pb;
-            }
-        }
-    }
-}
-
-// mapped key of element i as (hi, lo) unsigned 128-bit
-__device__ __forceinline__ void mapped_key(const uint8_t* e, uint32_t key_offset, uint32_t key_bytes, uint32_t kind,
-                                           uint64_t& lo, uint64_t& hi) {
-    lo = hi = 0;
-    const uint32_t top = key_bytes - 1;
-    const bool neg = (kind == 2) && (e[key_offset + top] & 0x80);
-    for (uint32_t k = 0; k < key_bytes; ++k) {
-        uint32_t b = e[key_offset + k];
-        if (neg) b ^= 0xFF;
-        else if (k == top && kind != 0) b ^= 0x80;
-        if (k < 8) lo |= (uint64_t)b << (8 * k);
-        else hi |= (uint64_t)b << (8 * (k - 8));
-    }
-}
-
-// Order-preserving signed 64-bit form of every key (keys of up to 8 bytes): the mapped key
-// (radix_digits.rs) zero-extended, with the top bit flipped so that signed comparison of the
-// outputs equals the sort order.  Used by the multi-GPU driver to locate its splitters by
-// binary search in locally sorted slices.
-__global__ __launch_bounds__(256) void rsx_extract_keys_kernel(const uint8_t* __restrict__ data, uint64_t n,
-                                                               uint32_t elem_bytes, uint32_t key_offset,
-                                                               uint32_t key_bytes, uint32_t kind,
-                                                               long long* __restrict__ out) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        uint64_t lo, hi;
-        mapped_key(data + i * elem_bytes, key_offset, key_bytes, kind, lo, hi);
-        out[i] = (long long)(lo ^ 0x8000000000000000ull);
-    }
-}
-
-// Lower and upper bound of 128-bit mapped-key queries in a slice that is sorted by mapped key:
-// out[qi] = number of elements with key < Q, out[nq + qi] = number with key <= Q.  One thread per
-// query; the multi-GPU splitter search (rsx_sort_sharded) asks a few hundred at a time.
-__global__ __launch_bounds__(256) void rsx_bounds_kernel(const uint8_t* __restrict__ data, uint64_t n,
-                                                         uint32_t elem_bytes, uint32_t key_offset, uint32_t key_bytes,
-                                                         uint32_t kind, const uint64_t* __restrict__ q, uint32_t nq,
-                                                         uint64_t* __restrict__ out) {
-    const uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (qi >= nq) return;
-    const uint64_t qlo = q[2 * qi], qhi = q[2 * qi + 1];
-    uint64_t lo = 0, hi = n;
-    while (lo < hi) {  // first element with key >= Q
-        const uint64_t mid = lo + (hi - lo) / 2;
-        uint64_t klo, khi;
-        mapped_key(data + mid * elem_bytes, key_offset, key_bytes, kind, klo, khi);
-        if (khi < qhi || (khi == qhi && klo < qlo)) lo = mid + 1;
-        else hi = mid;
-    }
-    out[qi] = lo;
-    hi = n;
-    while (lo < hi) {  // first element with key > Q
-        const uint64_t mid = lo + (hi - lo) / 2;
-        uint64_t klo, khi;
-        mapped_key(data + mid * elem_bytes, key_offset, key_bytes, kind, klo, khi);
-        if (khi < qhi || (khi == qhi && klo <= qlo)) lo = mid + 1;
-        else hi = mid;
-    }
-    out[nq + qi] = lo;
-}
-
-__global__ __launch_bounds__(256) void rsx_verify_kernel(const uint8_t* __restrict__ data, uint64_t n,
-                                                         uint32_t elem_bytes, uint32_t key_offset, uint32_t key_bytes,
-                                                         uint32_t kind, uint64_t* __restrict__ out) {
-    uint64_t bad = 0, sum = 0, unstable = 0;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint32_t pay_bytes = elem_bytes - key_bytes;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint8_t* e = data + i * elem_bytes;
-        uint64_t lo, hi;
-        mapped_key(e, key_offset, key_bytes, kind, lo, hi);
-        uint64_t h = 0x243F6A8885A308D3ull;
-        for (uint32_t b = 0; b < elem_bytes; b++) h = splitmix64(h ^ e[b]);
-        sum += h;
-        if (i + 1 < n) {
-            const uint8_t* f = e + elem_bytes;
-            uint64_t lo2, hi2;
-            mapped_key(f, key_offset, key_bytes, kind, lo2, hi2);
-            if (hi > hi2 || (hi == hi2 && lo > lo2)) ++bad;
-            if (pay_bytes && hi == hi2 && lo == lo2) {
-                uint64_t p1 = 0, p2 = 0;
-                uint32_t pb = 0;
-                for (uint32_t b = 0; b < elem_bytes && pb < 8; ++b) {
-                    if (b >= key_offset && b < key_offset + key_bytes) continue;
-                    p1 |= (uint64_t)e[b] << (8 * pb);
-                    p2 |= (uint64_t)f[b] << (8 * pb);
-                    ++pb;
-                }
-                if (p1 > p2) ++unstable;
-            }
-        }
-    }
-    // wave reduce then one atomic per wave
-    for (int o = 32; o > 0; o >>= 1) {
-        bad += __shfl_down(bad, o);
-        sum += __shfl_down(sum, o);
-        unstable += __shfl_down(unstable, o);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        if (bad) atomicAdd((unsigned long long*)&out[0], (unsigned long long)bad);
-        atomicAdd((unsigned long long*)&out[1], (unsigned long long)sum);
-        if (unstable) atomicAdd((unsigned long long*)&out[2], (unsigned long long)unstable);
-    }
 }
 
 }  // namespace rsx

@@ -1,0 +1,246 @@
+// rsx_internal.hpp -- host-side state and helpers shared by the translation units of librsx.so:
+//   rsx.hip     the C-ABI of include/rsx.h (context, pass loop, multi-GPU driver, harness)
+//   rsx_es.hip  the kernel launchers of ONE element size (compiled once per size with -DRSX_ES=n,
+//               so the eight sizes build in parallel)
+#pragma once
+#include "rsx_device.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <algorithm>
+#include <string>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "../../include/rsx.h"
+
+namespace rsxh {
+using namespace rsx;
+
+// aux block layout (one hipMalloc, zeroed at creation).  A sort zeroes [OFF_J0, OFF_ZERO_END)
+// with ONE memset before its count kernel: the first two count matrices and every pass's
+// ticket / roll-call words.  The third count matrix is zeroed by the first sweep.
+constexpr int MAX_PASSES = 16;                                                   // u128 keys
+constexpr size_t J_BYTES = (size_t)MAX_REGIONS * RADIX * sizeof(uint64_t);       // one count matrix
+constexpr size_t TICKET_WORDS = MAX_REGIONS + 2;                                 // per pass: tickets + roll call
+constexpr size_t OFF_J0 = 0;
+constexpr size_t OFF_J1 = OFF_J0 + J_BYTES;
+constexpr size_t OFF_TICKETS = OFF_J1 + J_BYTES;                                 // [MAX_PASSES][TICKET_WORDS] u32
+constexpr size_t OFF_ZERO_END = OFF_TICKETS + ((MAX_PASSES * TICKET_WORDS * 4 + 255) / 256) * 256;
+constexpr size_t OFF_J2 = OFF_ZERO_END;
+constexpr size_t OFF_BASE = OFF_J2 + J_BYTES;                                    // [MAX_REGIONS][256] cursors (API paths)
+constexpr size_t OFF_FLAGS = OFF_BASE + J_BYTES;                                 // self-test verdicts
+constexpr size_t OFF_DBG = OFF_FLAGS + 256;                                      // 16 waves x 8 diagnostic counters
+constexpr size_t AUX_BYTES = OFF_DBG + 1024;
+
+// option bits (rsx_ctx_set_option): alternative kernel paths, all bit-exact
+enum : uint32_t {
+    OPT_DYNAMIC_TILES = 1u << 0,   // ticketed tiles, no roll call
+    OPT_BALLOT_RANKS = 1u << 1,    // never rank by returned LDS atomics
+    OPT_ATOMIC_RANKS = 1u << 2,    // atomics whatever the skew
+    OPT_AGENT_STATUS = 1u << 3,    // agent-scope status stores everywhere
+    OPT_NO_XCD_MAJOR = 1u << 4,    // plain blockIdx numbering
+    OPT_GENERAL_BYTES = 1u << 5,   // one-byte elements through the general pass
+    OPT_VERBOSE = 1u << 6,
+};
+
+}  // namespace rsxh
+
+struct rsx_ctx {
+    int device = 0;
+    std::mutex mu;
+    std::string err = "";
+    void* status = nullptr;  // tile status words: two halves, alternating per pass
+    size_t status_bytes = 0;
+    char* aux = nullptr;
+    uint32_t* host_err = nullptr;  // pinned, device-mapped: a kernel that gives up sets it (no sync needed to see it)
+    uint32_t* host_err_dev = nullptr;
+    // staging for rsx_sort_host
+    void* host_buf[2] = {nullptr, nullptr};
+    size_t host_bytes = 0;
+    hipStream_t copy_stream[2] = {nullptr, nullptr};
+    void* pinned[4] = {nullptr, nullptr, nullptr, nullptr};  // ring of pinned bounce chunks
+    hipEvent_t copy_event[4] = {nullptr, nullptr, nullptr, nullptr};
+    // multi-GPU driver (rsx_sort_sharded): per-slice stream and splitter-search scratch, made once
+    hipStream_t shard_stream = nullptr;
+    uint64_t* shard_q = nullptr;     // device: queries (lo, hi) + ranges (begin, end)
+    uint64_t* shard_out = nullptr;   // device: answers
+    uint64_t* shard_hist = nullptr;  // device: 256 digit counts
+    uint64_t* shard_host = nullptr;  // pinned: answers, then the 256 counts
+    std::vector<uint64_t> shard_stage;
+    int num_cu = 256;
+    uint32_t pass_index = 0;   // of the sweep being launched within its sort (selects the status half, J rotation)
+    bool pass_last = true;     // no pass follows: nothing to clean
+    bool rank_atomic = false;  // LDS atomic ordering self-test passed (set when the workspace is first made)
+    bool l2_local = false;     // same-XCD hand-off self-test passed: chains may keep status words in their L2
+    uint32_t hot_lanes = 16;
+    uint32_t options = 0;      // OPT_* (rsx_ctx_set_option)
+    uint32_t max_regions = 0;  // 0 = default per element size
+    uint32_t dbg = 0;          // RSX_TUNING builds only: timing ablations (wrong output by design)
+    // stream-ordered reuse: work of this context on another stream waits for the last enqueue
+    hipStream_t last_stream = nullptr;
+    hipEvent_t last_event = nullptr;
+    bool busy = false;
+    // per-launch HIP-event timing (rsx_ctx_profile)
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending[RSX_PROF_KINDS];
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_free;
+    double prof_ms[RSX_PROF_KINDS] = {0, 0, 0, 0};
+    uint64_t prof_n[RSX_PROF_KINDS] = {0, 0, 0, 0};
+};
+
+namespace rsxh {
+
+inline int fail(rsx_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
+    if (c) {
+        c->err = what;
+        if (e != hipSuccess) {
+            c->err += ": ";
+            c->err += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+#define RSX_HIP(call)                                                   \
+    do {                                                                \
+        hipError_t _e = (call);                                         \
+        if (_e != hipSuccess) return fail(ctx, RSX_ERR_HIP, #call, _e); \
+    } while (0)
+
+// Records a start/stop event pair around one launch when profiling is on.
+struct LaunchTimer {
+    rsx_ctx* c;
+    int kind;
+    hipStream_t st;
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    LaunchTimer(rsx_ctx* ctx, int k, hipStream_t s) : c(ctx), kind(k), st(s) {
+        if (!c->prof) return;
+        if (!c->prof_free.empty()) {
+            ev = c->prof_free.back();
+            c->prof_free.pop_back();
+        } else if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) {
+            ev = {nullptr, nullptr};
+            return;
+        }
+        (void)hipEventRecord(ev.first, st);
+    }
+    ~LaunchTimer() {
+        if (!ev.first) return;
+        (void)hipEventRecord(ev.second, st);
+        c->prof_pending[kind].push_back(ev);
+    }
+};
+
+// Keys per thread by element size.  Tiles need not be powers of two (the last tile of a region is
+// partial anyway); bigger tiles mean longer output runs per digit (fewer partial cache lines, the
+// memory system's real cost here) and fewer look-backs per key, as long as two or three workgroups
+// still fit a CU: u32 28 x 512 = 14336 keys (56 KiB), u64 12 x 512 (48 KiB), 16-byte 5 x 512 (40 KiB),
+// 12-byte 10 x 512 (60 KiB), 24/32-byte 3 x 512 (36/48 KiB).
+// Measured against 16 / 8 / 4: 1B u32 117 -> 136, 1B u64 32 -> 34.9, 128M (u64,u64) 17.3 -> 18 Gkeys/s.
+#ifndef RSX_KPT4
+#define RSX_KPT4 28
+#endif
+#ifndef RSX_WG4
+#define RSX_WG4 512
+#endif
+#ifndef RSX_KPT8
+#define RSX_KPT8 12
+#endif
+#ifndef RSX_KPT16
+#define RSX_KPT16 5
+#endif
+#ifndef RSX_KPT12
+#define RSX_KPT12 10
+#endif
+#ifndef RSX_KPT32
+#define RSX_KPT32 3
+#endif
+#ifndef RSX_WG8
+#define RSX_WG8 512
+#endif
+constexpr int kpt_for(int es) { return es <= 4 ? RSX_KPT4 : es == 8 ? RSX_KPT8 : es == 12 ? RSX_KPT12 : es == 16 ? RSX_KPT16 : RSX_KPT32; }
+constexpr int wg_for(int es) { return es <= 4 ? RSX_WG4 : es == 8 ? RSX_WG8 : 512; }
+constexpr uint32_t tile_elems(int es) { return wg_for(es) * kpt_for(es); }
+
+inline uint32_t log2u(uint64_t x) { return 63u - (uint32_t)__builtin_clzll(x); }
+
+// Regions: smallest power-of-two length (>= one tile) that covers n with <= cap of them.
+inline RegionGeom make_geom(const rsx_ctx* ctx, uint64_t n, uint32_t es) {
+    RegionGeom g;
+    g.n = n;
+    uint32_t k = log2u(tile_elems((int)es));
+    if ((1ull << k) < tile_elems((int)es)) ++k;  // tiles need not be a power of two; regions are
+    // the next pass's count matrix costs 1 KiB of LDS per region: 8 where the tile needs the room
+    const uint64_t cap = ctx->max_regions ? ctx->max_regions : (es == 8 || es > 16) ? 16 : 8;
+    while (((n + (1ull << k) - 1) >> k) > cap) ++k;
+    g.region_shift = k;
+    g.num_regions = (uint32_t)((n + (1ull << k) - 1) >> k);
+    if (g.num_regions == 0) g.num_regions = 1;
+    return g;
+}
+inline uint64_t tiles_per_region(const RegionGeom& g, uint32_t es) {
+    const uint64_t t = tile_elems((int)es);
+    return ((1ull << g.region_shift) + t - 1) / t;
+}
+inline uint64_t status_rows(const RegionGeom& g, uint32_t es) {
+    return (uint64_t)g.num_regions * tiles_per_region(g, es);
+}
+// chain prefixes are relative to the region: 30 value bits suffice up to 2^30-element regions
+inline bool status32(const RegionGeom& g) { return g.region_shift <= 30; }
+
+inline DigitSpec make_spec(const rsx_layout* L, uint32_t digit) {
+    DigitSpec s;
+    const uint32_t byte = L->key_offset + digit;
+    const uint32_t top = L->key_offset + L->key_bytes - 1;
+    if (L->elem_bytes >= 4) {
+        s.word = byte >> 2;
+        s.shift = 8 * (byte & 3);
+        s.top_word = top >> 2;
+        s.top_shift = 8 * (top & 3) + 7;
+    } else {  // 1- and 2-byte elements live in one register
+        s.word = 0;
+        s.shift = 8 * byte;
+        s.top_word = 0;
+        s.top_shift = 8 * top + 7;
+    }
+    s.flip = (L->key_kind != RSX_KEY_UNSIGNED && digit == L->key_bytes - 1) ? 0x80u : 0u;
+    s.fsign = L->key_kind == RSX_KEY_FLOAT ? ~0u : 0u;
+    return s;
+}
+
+// the three count matrices rotate: pass d reads J_of(d % 3), accumulates the next pass's into
+// J_of((d + 1) % 3) and zeroes J_of((d + 2) % 3) for the pass after
+inline unsigned long long* J_of(rsx_ctx* c, uint32_t which) {
+    const size_t off = which == 0 ? OFF_J0 : which == 1 ? OFF_J1 : OFF_J2;
+    return reinterpret_cast<unsigned long long*>(c->aux + off);
+}
+inline uint64_t* base_of(rsx_ctx* c) { return reinterpret_cast<uint64_t*>(c->aux + OFF_BASE); }
+inline uint32_t* tickets_of(rsx_ctx* c, uint32_t pass) {
+    return reinterpret_cast<uint32_t*>(c->aux + OFF_TICKETS) + (size_t)pass * TICKET_WORDS;
+}
+inline uint32_t* flags_of(rsx_ctx* c) { return reinterpret_cast<uint32_t*>(c->aux + OFF_FLAGS); }
+
+// ---- per-element-size launchers (defined in rsx_launch_impl.hpp, instantiated in rsx_es.hip) ----
+// count phase of a first pass: J[r][v] for `digit` over the input regions (J zeroed by the caller)
+template <int ES>
+int launch_hist(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_layout* L, uint32_t digit,
+                unsigned long long* J, hipStream_t st);
+// one sweep pass.  J: this pass's count matrix; jnext: accumulated for the next pass (or null);
+// jzero: matrix to clear for the pass after next (or null); xf: bit 0 = map signed/float keys on
+// load (first pass), bit 1 = map back on store (last pass)
+template <int ES>
+int launch_sweep(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L, uint32_t digit,
+                 const unsigned long long* J, unsigned long long* jnext, unsigned long long* jzero, int xf,
+                 hipStream_t st);
+template <int ES>
+int launch_segcopy(rsx_ctx* ctx, const void* src, void* dst, const uint64_t* so, const uint64_t* dof,
+                   const uint64_t* len, uint32_t nseg, hipStream_t st);
+
+}  // namespace rsxh

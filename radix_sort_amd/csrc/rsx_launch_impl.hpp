@@ -1,0 +1,193 @@
+// rsx_launch_impl.hpp -- definitions of the per-element-size launchers declared in
+// rsx_internal.hpp.  Included only by rsx_es.hip, which instantiates them for ONE element size.
+#pragma once
+#include "rsx_internal.hpp"
+
+#ifndef RSX_HIST_BLOCKS_PER_CU
+#define RSX_HIST_BLOCKS_PER_CU 8
+#endif
+
+namespace rsxh {
+
+// ---- count phase of a first pass: J[r][v] for `digit` over the input regions ------------------
+template <int ES, bool FLT>
+int launch_hist_t(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_layout* L, uint32_t digit,
+                  unsigned long long* J, hipStream_t st) {
+    const uint64_t per_block = 512ull * 16;
+    uint64_t bpr = ((1ull << g.region_shift) + per_block - 1) / per_block;
+    const uint64_t cap = ((uint64_t)ctx->num_cu * RSX_HIST_BLOCKS_PER_CU + g.num_regions - 1) / g.num_regions;
+    if (bpr > cap) bpr = cap;
+    if (bpr == 0) bpr = 1;
+    LaunchTimer lt(ctx, RSX_PROF_HIST, st);
+    hipLaunchKernelGGL((rsx_hist_kernel<ES, FLT>), dim3((uint32_t)(bpr * g.num_regions)), dim3(512), 0, st,
+                       static_cast<const Elem<ES>*>(src), g, make_spec(L, digit), (uint32_t)bpr, J);
+    RSX_HIP(hipGetLastError());
+    return RSX_OK;
+}
+template <int ES>
+int launch_hist(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_layout* L, uint32_t digit,
+                unsigned long long* J, hipStream_t st) {
+    if (L->key_kind == RSX_KEY_FLOAT || (L->key_kind == RSX_KEY_SIGNED && digit + 1 == L->key_bytes))
+        return launch_hist_t<ES, true>(ctx, src, g, L, digit, J, st);
+    return launch_hist_t<ES, false>(ctx, src, g, L, digit, J, st);
+}
+
+// ---- scatter phase: one sweep pass -------------------------------------------------------------
+// the per-dword masks of the signed/float key map (KeyXform in rsx_device.hpp)
+inline KeyXform make_xform(const rsx_layout* L) {
+    KeyXform x;
+    std::memset(&x, 0, sizeof x);
+    if (L->key_kind == RSX_KEY_UNSIGNED) return x;
+    const uint32_t top = L->key_offset + L->key_bytes - 1;
+    auto word_of = [&](uint32_t byte) { return L->elem_bytes >= 4 ? byte >> 2 : 0u; };
+    auto bit_of = [&](uint32_t byte) { return L->elem_bytes >= 4 ? 8 * (byte & 3) : 8 * byte; };
+    const uint32_t sw = word_of(top);
+    const uint32_t sbit = 1u << (bit_of(top) + 7);
+    x.sign[sw] = sbit;
+    x.xpos[sw] = sbit;
+    if (L->key_kind == RSX_KEY_SIGNED) {
+        x.xneg[sw] = sbit;
+    } else {
+        for (uint32_t b = L->key_offset; b <= top; ++b) x.xneg[word_of(b)] |= 0xFFu << bit_of(b);
+    }
+    return x;
+}
+
+template <int ES, typename S, int XF, bool NEXT>
+int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L,
+                   uint32_t digit, const unsigned long long* J, unsigned long long* jnext, unsigned long long* jzero,
+                   hipStream_t st) {
+    constexpr int KPT = kpt_for(ES);
+    constexpr int SWEEP_WG = wg_for(ES);
+    constexpr int TILE = SWEEP_WG * KPT;
+    const uint64_t rows = status_rows(g, ES);
+    // Status words alternate between the two halves of the workspace.  Only the first pass of a
+    // sort zeroes its half with a memset; every pass zeroes, tile by tile, the half of the next.
+    char* const half[2] = {static_cast<char*>(ctx->status), static_cast<char*>(ctx->status) + ctx->status_bytes};
+    const uint32_t which = ctx->pass_index & 1u;
+    if (ctx->pass_index == 0) RSX_HIP(hipMemsetAsync(half[0], 0, (size_t)rows * RADIX * sizeof(S), st));
+    SweepArgs a;
+    a.status_clean = ctx->pass_last ? nullptr : half[which ^ 1u];
+    a.src = src;
+    a.dst = dst;
+    a.g = g;
+    a.J = J;
+    a.status = half[which];
+    a.tickets = tickets_of(ctx, ctx->pass_index);
+    a.prev_mode = ctx->pass_index ? tickets_of(ctx, ctx->pass_index - 1) + MAX_REGIONS + 1 : nullptr;
+    a.jnext = jnext;
+    a.jzero = jzero;
+    a.error = ctx->host_err_dev;
+    a.spec = make_spec(L, digit);
+    a.next = make_spec(L, NEXT ? digit + 1 : digit);
+    a.spec.flip = a.next.flip = 0;  // the sweep sees mapped keys: plain digits
+    a.xf = make_xform(L);
+    a.tiles_per_region = (uint32_t)tiles_per_region(g, ES);
+    a.opts = ((ctx->options & OPT_DYNAMIC_TILES) ? SWEEP_OPT_DYNAMIC : 0u) |
+             ((ctx->options & OPT_NO_XCD_MAJOR) ? SWEEP_OPT_NO_XCD_MAJOR : 0u) |
+             ((ctx->options & OPT_AGENT_STATUS) || !ctx->l2_local ? SWEEP_OPT_AGENT_STATUS : 0u);
+    a.dbg = ctx->dbg;
+    a.rank_atomic = (ctx->rank_atomic && !(ctx->options & OPT_BALLOT_RANKS)) ? 1u : 0u;
+    a.hot_lanes = (ctx->options & OPT_ATOMIC_RANKS) ? 65u : ctx->hot_lanes;
+    a.dbg_cnt = reinterpret_cast<unsigned long long*>(ctx->aux + OFF_DBG);
+    const size_t lds = (size_t)TILE * ES + (SWEEP_WG / WAVE) * RADIX * ((RSX_WIDE_CNT && ES <= 4 && KPT >= 16 && SWEEP_WG <= 512) ? sizeof(uint32_t) : sizeof(uint16_t)) +
+                       (NEXT ? (size_t)g.num_regions * RADIX * sizeof(uint32_t) : 0) + 128;
+    auto kern = rsx_sweep_kernel<ES, KPT, SWEEP_WG, S, XF, NEXT>;
+    // resident workgroups per CU for this kernel at this LDS size (the count matrix of the next pass
+    // makes the LDS size depend on the number of regions): cached per instantiation and thread
+    thread_local size_t occ_lds = ~(size_t)0;
+    thread_local int occ = 0;
+    if (occ == 0 || occ_lds != lds) {
+        int o = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kern, SWEEP_WG, lds) != hipSuccess || o < 1) o = 2;
+        occ = o;
+        occ_lds = lds;
+    }
+    // persistent workgroups; correctness does not need them co-resident (a workgroup only
+    // ever waits for tiles whose tickets were drawn earlier, by workgroups already running)
+    const uint64_t total_tiles = (g.n + TILE - 1) / TILE + g.num_regions;
+    uint64_t grid = (uint64_t)ctx->num_cu * occ;
+    if (grid > total_tiles) grid = total_tiles;
+#ifdef RSX_TUNING
+    if (const char* o = std::getenv("RSX_OCC")) {
+        const long v = std::atol(o);
+        if (v >= 1 && v <= 8) grid = (uint64_t)ctx->num_cu * (uint64_t)v;
+    }
+#endif
+    if (grid > 0xFFFFu) grid = 0xFFFFu;  // wg_first entries are 16 bit
+    {   // static mode: workgroups per region, proportional to the region's tile count, >= 1 each
+        const uint32_t NR = g.num_regions;
+        const uint64_t tpr = tiles_per_region(g, ES);
+        const uint64_t real_tiles = (g.n + TILE - 1) / TILE;
+        uint64_t cum = 0;
+        for (uint32_t r = 0; r < NR; ++r) {
+            a.wg_first[r] = (uint16_t)(cum * grid / real_tiles);
+            const uint64_t left = real_tiles - cum;
+            cum += left < tpr ? left : tpr;
+        }
+        a.wg_first[NR] = (uint16_t)grid;
+        for (uint32_t r = 0; r < NR; ++r)  // at least one workgroup per region
+            if (a.wg_first[r + 1] <= a.wg_first[r]) a.wg_first[r + 1] = a.wg_first[r] + 1;
+        for (uint32_t r = NR; r-- > 0;) {
+            const uint32_t cap = (uint32_t)grid - (NR - r);
+            if (a.wg_first[r] > cap) a.wg_first[r] = (uint16_t)cap;
+        }
+        a.wg_first[NR] = (uint16_t)grid;
+        for (uint32_t r = NR + 1; r <= (uint32_t)MAX_REGIONS; ++r) a.wg_first[r] = (uint16_t)grid;
+        // regions whose workgroups fall into one class of the kernel's XCD-major numbering
+        // (class = index / (grid/8) = blockIdx % 8): candidates for L2-local status words
+        a.local_mask = 0;
+        if (grid % 8 == 0 && !(ctx->options & OPT_NO_XCD_MAJOR))
+            for (uint32_t r = 0; r < NR; ++r)
+                if (a.wg_first[r] / (grid / 8) == (a.wg_first[r + 1] - 1u) / (grid / 8)) a.local_mask |= 1u << r;
+    }
+    if (ctx->options & OPT_VERBOSE) std::fprintf(stderr, "[rsx] sweep ES=%d NEXT=%d occ=%d grid=%llu lds=%zu tiles=%llu regions=%u\n", ES, (int)NEXT, occ, (unsigned long long)grid, lds, (unsigned long long)total_tiles, g.num_regions);
+    LaunchTimer lt(ctx, RSX_PROF_SWEEP, st);
+    hipLaunchKernelGGL(kern, dim3((uint32_t)grid), dim3(SWEEP_WG), lds, st, a);
+    RSX_HIP(hipGetLastError());
+    return RSX_OK;
+}
+
+template <int ES, typename S, int XF>
+int launch_sweep_n(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L,
+                   uint32_t digit, const unsigned long long* J, unsigned long long* jnext, unsigned long long* jzero,
+                   hipStream_t st) {
+    if constexpr ((XF & 2) == 0) {  // a pass that maps the keys back is a last pass: nothing to count for
+        if (jnext) return launch_sweep_t<ES, S, XF, true>(ctx, src, dst, g, L, digit, J, jnext, jzero, st);
+    } else if (jnext) {
+        return fail(ctx, RSX_ERR_ARG, "a last pass cannot count for a next one");
+    }
+    return launch_sweep_t<ES, S, XF, false>(ctx, src, dst, g, L, digit, J, nullptr, jzero, st);
+}
+
+template <int ES, typename S>
+int launch_sweep_x(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L,
+                   uint32_t digit, const unsigned long long* J, unsigned long long* jnext, unsigned long long* jzero,
+                   int xf, hipStream_t st) {
+    switch (L->key_kind == RSX_KEY_UNSIGNED ? 0 : xf) {
+        case 1: return launch_sweep_n<ES, S, 1>(ctx, src, dst, g, L, digit, J, jnext, jzero, st);
+        case 2: return launch_sweep_n<ES, S, 2>(ctx, src, dst, g, L, digit, J, jnext, jzero, st);
+        case 3: return launch_sweep_n<ES, S, 3>(ctx, src, dst, g, L, digit, J, jnext, jzero, st);
+        default: return launch_sweep_n<ES, S, 0>(ctx, src, dst, g, L, digit, J, jnext, jzero, st);
+    }
+}
+
+template <int ES>
+int launch_sweep(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L, uint32_t digit,
+                 const unsigned long long* J, unsigned long long* jnext, unsigned long long* jzero, int xf,
+                 hipStream_t st) {
+    if (status32(g)) return launch_sweep_x<ES, uint32_t>(ctx, src, dst, g, L, digit, J, jnext, jzero, xf, st);
+    return launch_sweep_x<ES, uint64_t>(ctx, src, dst, g, L, digit, J, jnext, jzero, xf, st);
+}
+
+template <int ES>
+int launch_segcopy(rsx_ctx* ctx, const void* src, void* dst, const uint64_t* so, const uint64_t* dof,
+                   const uint64_t* len, uint32_t nseg, hipStream_t st) {
+    const uint32_t bps = 8;
+    hipLaunchKernelGGL((rsx_segcopy_kernel<ES>), dim3(nseg * bps), dim3(256), 0, st,
+                       static_cast<const Elem<ES>*>(src), static_cast<Elem<ES>*>(dst), so, dof, len, nseg, bps);
+    RSX_HIP(hipGetLastError());
+    return RSX_OK;
+}
+
+}  // namespace rsxh

@@ -1,0 +1,378 @@
+// rsx_misc_kernels.hpp -- the kernels that do not depend on the element size: digit totals, the
+// one-byte counting path, the two device self-tests, the multi-GPU splitter search and the harness
+// (generators, verifier).  Included by rsx.hip only (one definition per library).
+#pragma once
+#include "rsx_device.hpp"
+
+namespace rsx {
+
+// The 256 digit totals of a count matrix (column sums over the regions): what the per-pass
+// building blocks hand to the multi-GPU driver, and what the one-byte counting path expands.
+// The prefix phase proper (mod.rs:110-120) runs inside the sweep kernel's prologue.
+__global__ __launch_bounds__(256) void rsx_totals_kernel(const unsigned long long* __restrict__ J,
+                                                         uint32_t num_regions, uint64_t* __restrict__ counts_out) {
+    const uint32_t tid = threadIdx.x;
+    uint64_t c = 0;
+    for (uint32_t r = 0; r < num_regions; ++r) c += J[r * RADIX + tid];
+    counts_out[tid] = c;
+}
+
+// ------------------------------------------------------------ one-byte elements --
+// An element that IS its one-byte key (u8, i8) is fully described by its digit: the sorted array is
+// the 256 counts written out as runs (counting sort: one read of the data, one write, no scatter).
+// `counts` are by mapped digit (the count kernel maps signed keys); byte = mapped value ^ xor_mask.
+__global__ __launch_bounds__(256) void rsx_expand_bytes_kernel(uint8_t* __restrict__ dst, uint64_t n,
+                                                               const uint64_t* __restrict__ counts,
+                                                               uint32_t xor_mask) {
+    __shared__ uint64_t start[RADIX + 1];
+    __shared__ uint64_t wsum[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint64_t x = counts[tid];
+    const uint64_t c = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t y = __shfl_up(x, o);
+        if (lane >= (uint32_t)o) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    uint64_t wb = 0;
+    for (uint32_t w = 0; w < wave; ++w) wb += wsum[w];
+    start[tid] = wb + x - c;
+    if (tid == RADIX - 1) start[RADIX] = wb + x;
+    __syncthreads();
+    const bool wide = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;  // 16-byte stores need the alignment
+    const uint64_t chunks = (n + 15) / 16;
+    for (uint64_t ch = (uint64_t)blockIdx.x * blockDim.x + tid; ch < chunks; ch += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t p0 = ch * 16;
+        uint32_t lo = 0, hi = RADIX;  // last v with start[v] <= p0
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) / 2;
+            if (start[mid] <= p0) lo = mid;
+            else hi = mid;
+        }
+        uint32_t v = lo;
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            while (v < RADIX - 1 && start[v + 1] <= p0 + k) ++v;  // empty digits are stepped over
+            w[k / 4] |= ((v ^ xor_mask) & 0xFFu) << (8 * (k % 4));
+        }
+        if (wide && p0 + 16 <= n) {
+            *reinterpret_cast<uint4*>(dst + p0) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+            for (int k = 0; k < 16 && p0 + k < n; ++k) dst[p0 + k] = (uint8_t)(w[k / 4] >> (8 * (k % 4)));
+        }
+    }
+}
+
+// ------------------------------------------------------------------ harness --
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ uint64_t rand64(uint64_t seed, uint64_t index) {
+    return splitmix64(seed + index * 0x9E3779B97F4A7C15ull);
+}
+
+// ------------------------------------------------------------- LDS atomic order --
+// Self-test behind a.rank_atomic: when several lanes of ONE ds_add_rtn instruction hit the same
+// address, the sweep needs them applied in ascending lane order (then the returned values are
+// stable ranks).  The ISA documents no order, so it is established on the device at hand: 64
+// address patterns (1..256 distinct addresses; hashed, lane-cyclic, blocked and same-bank layouts;
+// both the 32-bit and the packed 16-bit counter forms), every lane checks its two returned values
+// against the ballot-derived rank.  Any mismatch sets *fail and the sweep keeps to ballots.
+__global__ __launch_bounds__(512) void rsx_lds_order_kernel(uint32_t* __restrict__ fail) {
+    __shared__ uint32_t cnt[8][RADIX];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    static constexpr uint32_t BINS[8] = {1, 2, 3, 5, 16, 64, 256, 256};
+    uint32_t bad = 0;
+    for (uint32_t p = 0; p < 64; ++p) {
+        for (uint32_t i = lane; i < RADIX; i += WAVE) cnt[wave][i] = 0;  // LDS serves one wave in order
+        const uint32_t bins = BINS[p & 7];
+        const uint32_t h = (uint32_t)(splitmix64(((uint64_t)blockIdx.x << 32) ^ (p << 16) ^ (wave << 8) ^ lane) >> 32);
+        uint32_t d;
+        switch ((p >> 3) & 3) {
+            case 0: d = h % bins; break;                        // hashed
+            case 1: d = lane % bins; break;                     // cyclic: neighbours differ
+            case 2: d = (lane * bins) / WAVE; break;            // blocked: neighbours share
+            default: d = ((h % bins) * 32u) % RADIX; break;     // distinct addresses in one bank
+        }
+        const uint64_t m = match_digit<8>(d);
+        const uint32_t below = mbcnt64(m), group = (uint32_t)__popcll(m);
+        uint32_t r1, r2;
+        if (p & 32) {  // packed: two 16-bit counters per word
+            const uint32_t sh = (d & 1u) * 16u;
+            r1 = (atomicAdd(&cnt[wave][d >> 1], 1u << sh) >> sh) & 0xFFFFu;
+            r2 = (atomicAdd(&cnt[wave][d >> 1], 1u << sh) >> sh) & 0xFFFFu;
+        } else {
+            r1 = atomicAdd(&cnt[wave][d], 1u);
+            r2 = atomicAdd(&cnt[wave][d], 1u);
+        }
+        if (r1 != below || r2 != group + below) bad = 1;
+    }
+    if (__ballot(bad != 0) != 0 && lane == 0) atomicOr(fail, 1u);
+}
+
+// ------------------------------------------------------------- same-XCD hand-off --
+// Self-test behind the L2-resident status words of a verified single-XCD chain (sweep kernel,
+// `local_chain`): is a WAVEFRONT-scope store (plain global_store: the line stays dirty in the XCD's
+// L2, nothing is written through) made on one CU seen by an AGENT-scope load (sc1: bypasses the
+// reader's L1, served by the L2) issued on ANOTHER CU of the same XCD, with no fence in between?
+// Blocks b and b + 8 are dealt to one XCD by the dispatcher as observed; the pair checks that itself
+// (HW_REG_XCC_ID) and whether it sits on two CUs (HW_REG_HW_ID), then plays ping-pong for `rounds`
+// values: A stores k (wavefront scope) and waits for the acknowledgement, B polls for k (agent
+// scope) and acknowledges (agent scope).  Every wait is bounded.
+// out[0] += pairs that ran the test on one XCD, out[1] += of those on two different CUs,
+// out[2] += pairs where a value did not arrive in time (the verdict: must stay 0).
+// words: per pair 4 x u32 {data, ack, meta_a, meta_b}, zeroed by the caller.
+__global__ __launch_bounds__(64) void rsx_l2_probe_kernel(uint32_t* __restrict__ words, uint32_t* __restrict__ out,
+                                                         uint32_t rounds) {
+    if (threadIdx.x != 0) return;
+    const uint32_t b = blockIdx.x;
+    const bool is_a = (b & 8u) == 0u;
+    const uint32_t pair = (b >> 4) * 8u + (b & 7u);
+    uint32_t* w = words + pair * 4u;
+    uint32_t xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    const uint32_t me = 0x80000000u | ((xcc & 0xFu) << 16) | ((hw >> 8) & 0xFFu);  // CU / SH / SE id bits of HW_ID
+    __hip_atomic_store(&w[is_a ? 2 : 3], me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t other = 0;
+    for (uint32_t spin = 0; spin < (1u << 18) && other == 0; ++spin) {
+        other = __hip_atomic_load(&w[is_a ? 3 : 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (other == 0) __builtin_amdgcn_s_sleep(2);
+    }
+    if (other == 0 || ((other ^ me) & 0x000F0000u) != 0) return;  // partner not running, or another XCD: no verdict from this pair
+    if (is_a) {
+        atomicAdd(&out[0], 1u);
+        if (((other ^ me) & 0xFFu) != 0) atomicAdd(&out[1], 1u);
+    }
+    for (uint32_t k = 1; k <= rounds; ++k) {
+        if (is_a) {
+            __hip_atomic_store(&w[0], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            uint32_t got = 0;
+            for (uint32_t spin = 0; spin < (1u << 16) && got != k; ++spin) {
+                got = __hip_atomic_load(&w[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (got != k) __builtin_amdgcn_s_sleep(1);
+            }
+            if (got != k) return;  // B reports the failure
+        } else {
+            uint32_t got = 0;
+            for (uint32_t spin = 0; spin < (1u << 15) && got != k; ++spin) {
+                got = __hip_atomic_load(&w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (got != k) __builtin_amdgcn_s_sleep(1);
+            }
+            if (got != k) {
+                atomicAdd(&out[2], 1u);
+                return;
+            }
+            __hip_atomic_store(&w[1], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ---- generators (harness; shapes of the reference's src/distr.rs) -------------------------------
+// Integer arithmetic only, so that the same (seed, index) gives the same key on the device and in
+// the CPU restatement the tests hold against them: no libm call whose last bit could differ.
+// 2^(2^-i) as 1.63 fixed point, i = 1..32
+__device__ static const uint64_t GEN_EXP2_TAB[32] = {
+    0xB504F333F9DE6484ull, 0x9837F0518DB8A96Full, 0x8B95C1E3EA8BD6E7ull, 0x85AAC367CC487B15ull,
+    0x82CD8698AC2BA1D7ull, 0x8164D1F3BC030773ull, 0x80B1ED4FD999AB6Cull, 0x8058D7D2D5E5F6B1ull,
+    0x802C6436D0E04F51ull, 0x8016302F17467628ull, 0x800B179C82028FD1ull, 0x80058BAF7FEE3B5Dull,
+    0x8002C5D00FDCFCB7ull, 0x800162E61BED4A49ull, 0x8000B17292F702A4ull, 0x800058B92ABBAE02ull,
+    0x80002C5C8DADE4D7ull, 0x8000162E44EAF636ull, 0x80000B1721FA7C19ull, 0x8000058B90DE7E4Dull,
+    0x800002C5C8678F37ull, 0x80000162E431DBA0ull, 0x800000B1721872D1ull, 0x80000058B90C1AA9ull,
+    0x8000002C5C8605A4ull, 0x800000162E4300E6ull, 0x8000000B17217FF8ull, 0x800000058B90BFDDull,
+    0x80000002C5C85FE7ull, 0x8000000162E42FF2ull, 0x80000000B17217F8ull, 0x8000000058B90BFCull};
+
+// floor(2^t) for t = e + f / 2^32, 0 <= e <= 63: the mantissa 2^(f/2^32) is the product of the table
+// entries of f's set bits, each product truncated to 1.63 fixed point
+__device__ __forceinline__ uint64_t gen_exp2_floor(uint32_t e, uint32_t f) {
+    uint64_t m = 1ull << 63;
+    for (int i = 0; i < 32; ++i)
+        if (f & (0x80000000u >> i)) m = __umul64hi(m, GEN_EXP2_TAB[i]) << 1;
+    return m >> (63u - e);
+}
+// -log2(w / 2^64) for w >= 1 as 32.32 fixed point: exponent from the leading zeros, 32 fraction bits
+// by repeated squaring of the 1.63 mantissa
+__device__ __forceinline__ uint64_t gen_neg_log2(uint64_t w) {
+    const uint32_t lz = (uint32_t)__builtin_clzll(w);
+    uint64_t m = w << lz;
+    uint32_t frac = 0;
+    for (int i = 0; i < 32; ++i) {
+        m = __umul64hi(m, m);  // 2.62 fixed point, in [1, 4)
+        if (m >> 63) frac |= 0x80000000u >> i;  // >= 2: this bit of the logarithm is set, m / 2 is back in 1.63
+        else m <<= 1;
+    }
+    return (64ull << 32) - ((((uint64_t)(63u - lz)) << 32) | frac);
+}
+
+// key (as up to 128 bits lo/hi) for generator `gen`.  iparam: generator-specific integer form of the
+// caller's `param`, made once on the host (rsx_generate_device).
+__device__ __forceinline__ void gen_key(int gen, uint64_t seed, double param, uint64_t iparam, uint64_t gi,
+                                        uint64_t n_total, uint32_t key_bytes, uint64_t& lo, uint64_t& hi) {
+    const uint32_t bits = key_bytes * 8;
+    lo = hi = 0;
+    switch (gen) {
+        case 0:  // uniform (distr.rs:40-52 `Standard`)
+            lo = rand64(seed, gi);
+            hi = rand64(seed ^ 0xA5A5A5A5A5A5A5A5ull, gi);
+            break;
+        case 1: {  // Zipf-shaped (distr.rs:54-76,108-130): continuous inverse of H(x) = (x^(1-s) - 1)/(1-s), N = 2^min(bits,64) - 1
+            const uint64_t r = rand64(seed, gi);
+            if (param == 1.0) {  // s = 1: x = 2^(u * bits), in fixed point (reproducible on the host)
+                const uint64_t t = (r >> 32) * (uint64_t)(bits >= 64 ? 64u : bits);  // 32.32
+                const uint64_t x = gen_exp2_floor((uint32_t)(t >> 32), (uint32_t)t);
+                lo = x - 1;  // x >= 1
+            } else {  // other exponents: double precision pow (device libm: the shape, not a host-reproducible bit pattern)
+                const double u = (double)(r >> 11) * (1.0 / 9007199254740992.0);
+                const double N1 = bits >= 64 ? 18446744073709551616.0 : (double)(1ull << bits);
+                double x = pow(1.0 + u * (pow(N1, 1.0 - param) - 1.0), 1.0 / (1.0 - param));
+                x = floor(x) - 1.0;
+                if (x < 0) x = 0;
+                lo = x >= 18446744073709551615.0 ? ~0ull : (uint64_t)x;
+            }
+            break;
+        }
+        case 2: {  // step-uniform over `param` equally spaced values (distr.rs:78-106,132-160)
+            const uint64_t k = iparam;
+            const uint64_t maxv = bits >= 64 ? ~0ull : ((1ull << bits) - 1);
+            const uint64_t s = maxv / (k + 1);
+            lo = s * (1 + rand64(seed, gi) % k);
+            break;
+        }
+        case 3: lo = gi; break;
+        case 4: lo = n_total - 1 - gi; break;
+        case 6: {  // geometric, success probability `param` (distr.rs:3-38 MyExp): floor(log2(U) / log2(1 - p)) by inversion;
+                   // iparam = -log2(1 - p) as 32.32 fixed point
+            uint64_t w = rand64(seed, gi);
+            if (w == 0) w = 1;
+            lo = gen_neg_log2(w) / iparam;
+            break;
+        }
+        default: lo = iparam; break;  // constant
+    }
+}
+
+// payload_zero: every byte outside the key is 0 (the reference's `(key, 0)` pairs, distr.rs:22-26,42-52);
+// else the payload holds the low bytes of the element's global index (reveals instability).
+__global__ __launch_bounds__(256) void rsx_generate_kernel(uint8_t* __restrict__ data, uint64_t n,
+                                                           uint32_t elem_bytes, uint32_t key_offset,
+                                                           uint32_t key_bytes, int gen, uint64_t seed, double param,
+                                                           uint64_t iparam, uint64_t index_base, uint32_t payload_zero) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t gi = index_base + i;
+        uint64_t lo, hi;
+        gen_key(gen, seed, param, iparam, gi, index_base + n, key_bytes, lo, hi);
+        uint8_t* e = data + i * elem_bytes;
+        uint32_t pb = 0;  // payload byte counter
+        for (uint32_t b = 0; b < elem_bytes; ++b) {
+            if (b >= key_offset && b < key_offset + key_bytes) {
+                const uint32_t kb = b - key_offset;
+                e[b] = (uint8_t)((kb < 8 ? lo >> (8 * kb) : hi >> (8 * (kb - 8))) & 0xFF);
+            } else {
+                e[b] = (pb < 8 && !payload_zero) ? (uint8_t)((gi >> (8 * pb)) & 0xFF) : 0;
+                ++pb;
+            }
+        }
+    }
+}
+
+// mapped key of element i as (hi, lo) unsigned 128-bit
+__device__ __forceinline__ void mapped_key(const uint8_t* e, uint32_t key_offset, uint32_t key_bytes, uint32_t kind,
+                                           uint64_t& lo, uint64_t& hi) {
+    lo = hi = 0;
+    const uint32_t top = key_bytes - 1;
+    const bool neg = (kind == 2) && (e[key_offset + top] & 0x80);
+    for (uint32_t k = 0; k < key_bytes; ++k) {
+        uint32_t b = e[key_offset + k];
+        if (neg) b ^= 0xFF;
+        else if (k == top && kind != 0) b ^= 0x80;
+        if (k < 8) lo |= (uint64_t)b << (8 * k);
+        else hi |= (uint64_t)b << (8 * (k - 8));
+    }
+}
+
+// Lower and upper bound of 128-bit mapped-key queries in a range that is sorted by mapped key:
+// out[qi] = number of elements of the range with key < Q, out[nq + qi] = number with key <= Q.  The
+// range of query qi is [ranges[2 qi], ranges[2 qi + 1]) of `data`, or all n elements when `ranges`
+// is null.  One thread per query; the multi-GPU splitter search asks a few hundred at a time.
+__global__ __launch_bounds__(256) void rsx_bounds_kernel(const uint8_t* __restrict__ data, uint64_t n,
+                                                         uint32_t elem_bytes, uint32_t key_offset, uint32_t key_bytes,
+                                                         uint32_t kind, const uint64_t* __restrict__ q, uint32_t nq,
+                                                         uint64_t* __restrict__ out, const uint64_t* __restrict__ ranges) {
+    const uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= nq) return;
+    const uint64_t qlo = q[2 * qi], qhi = q[2 * qi + 1];
+    const uint64_t begin = ranges ? ranges[2 * qi] : 0;
+    uint64_t end = ranges ? ranges[2 * qi + 1] : n;
+    if (end > n) end = n;
+    uint64_t lo = begin < end ? begin : end, hi = end;
+    while (lo < hi) {  // first element with key >= Q
+        const uint64_t mid = lo + (hi - lo) / 2;
+        uint64_t klo, khi;
+        mapped_key(data + mid * elem_bytes, key_offset, key_bytes, kind, klo, khi);
+        if (khi < qhi || (khi == qhi && klo < qlo)) lo = mid + 1;
+        else hi = mid;
+    }
+    out[qi] = lo - (begin < end ? begin : end);
+    hi = end;
+    while (lo < hi) {  // first element with key > Q
+        const uint64_t mid = lo + (hi - lo) / 2;
+        uint64_t klo, khi;
+        mapped_key(data + mid * elem_bytes, key_offset, key_bytes, kind, klo, khi);
+        if (khi < qhi || (khi == qhi && klo <= qlo)) lo = mid + 1;
+        else hi = mid;
+    }
+    out[nq + qi] = lo - (begin < end ? begin : end);
+}
+
+__global__ __launch_bounds__(256) void rsx_verify_kernel(const uint8_t* __restrict__ data, uint64_t n,
+                                                         uint32_t elem_bytes, uint32_t key_offset, uint32_t key_bytes,
+                                                         uint32_t kind, uint64_t* __restrict__ out) {
+    uint64_t bad = 0, sum = 0, unstable = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t pay_bytes = elem_bytes - key_bytes;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint8_t* e = data + i * elem_bytes;
+        uint64_t lo, hi;
+        mapped_key(e, key_offset, key_bytes, kind, lo, hi);
+        uint64_t h = 0x243F6A8885A308D3ull;
+        for (uint32_t b = 0; b < elem_bytes; b++) h = splitmix64(h ^ e[b]);
+        sum += h;
+        if (i + 1 < n) {
+            const uint8_t* f = e + elem_bytes;
+            uint64_t lo2, hi2;
+            mapped_key(f, key_offset, key_bytes, kind, lo2, hi2);
+            if (hi > hi2 || (hi == hi2 && lo > lo2)) ++bad;
+            if (pay_bytes && hi == hi2 && lo == lo2) {
+                uint64_t p1 = 0, p2 = 0;
+                uint32_t pb = 0;
+                for (uint32_t b = 0; b < elem_bytes && pb < 8; ++b) {
+                    if (b >= key_offset && b < key_offset + key_bytes) continue;
+                    p1 |= (uint64_t)e[b] << (8 * pb);
+                    p2 |= (uint64_t)f[b] << (8 * pb);
+                    ++pb;
+                }
+                if (p1 > p2) ++unstable;
+            }
+        }
+    }
+    // wave reduce then one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) {
+        bad += __shfl_down(bad, o);
+        sum += __shfl_down(sum, o);
+        unstable += __shfl_down(unstable, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (bad) atomicAdd((unsigned long long*)&out[0], (unsigned long long)bad);
+        atomicAdd((unsigned long long*)&out[1], (unsigned long long)sum);
+        if (unstable) atomicAdd((unsigned long long*)&out[2], (unsigned long long)unstable);
+    }
+}
+
+}  // namespace rsx

@@ -61,13 +61,6 @@ class HipBackend:
         s = self.torch.cuda.current_stream().cuda_stream
         self.ctx.sort_device(x.data_ptr(), tmp.data_ptr(), n, d, s)
 
-    def mapped_keys(self, x, n: int, d: RadixDigits):
-        """int64 tensor, signed order == sort order (rsx_extract_keys_device)."""
-        k = self.torch.empty(n, dtype=self.torch.int64, device=self.device)
-        s = self.torch.cuda.current_stream().cuda_stream
-        self.ctx.extract_keys_device(x.data_ptr(), n, d, k.data_ptr(), s)
-        return k
-
     def bounds(self, x, n: int, d: RadixDigits, q_lo: np.ndarray, q_hi: np.ndarray):
         """(less, less_or_equal) counts of the 128-bit mapped-key queries in the sorted slice x
         (rsx_bounds_device); numpy int64 arrays."""
@@ -125,22 +118,21 @@ def exchange_plan(H: np.ndarray, n_per_rank: np.ndarray, rank: int):
     return send_counts, recv_counts, segs
 
 
-def _signed64(u: np.ndarray) -> np.ndarray:
-    """unsigned 64-bit key values -> the signed form used by mapped_keys (top bit flipped)."""
-    return (u.astype(np.uint64) ^ np.uint64(1 << 63)).view(np.int64)
-
-
 class ShardedRadixSort:
     """`radix_sort` over a slice-per-rank array.  All ranks call `sort` collectively.
 
-    Two schedules with the same (unique) result:
-      * `sort`              one bucket exchange per pass -- the reference's loop with chunk == rank;
-      * `sort_one_exchange` sort locally, find the exact splitters of the destination slices by a
-                            256-way search over the key digits (one small all-reduce per digit),
-                            exchange ONCE, sort locally again (the received chunks arrive ordered by
-                            source rank, so a stable local sort reproduces the global stable order).
+    Three schedules with the same (unique) result:
+      * `sort`                one bucket exchange per pass -- the reference's loop with chunk == rank;
+      * `sort_one_exchange`   sort locally, find the exact splitters of the destination slices by a
+                              256-way search over the key digits (one small all-reduce per digit),
+                              exchange ONCE, sort locally again (the received chunks arrive ordered by
+                              source rank, so a stable local sort reproduces the global stable order);
+      * `sort_exchange_first` ONE stable partition pass by the most significant digit, the G x 256
+                              counts laid out globally (mod.rs:110-120 with chunk == rank); only the
+                              buckets that a slice boundary falls into are sorted locally and cut
+                              exactly; exchange ONCE; ONE local sort.  1 + D local passes instead of 2 D.
     xGMI moves (G-1)/G of every slice per exchange at a small fraction of HBM speed, so the number
-    of exchanges, not the local passes, decides multi-GPU throughput.
+    of exchanges first, then the local passes, decide multi-GPU throughput.
     """
 
     def __init__(self, group=None, backend=None):
@@ -248,6 +240,118 @@ class ShardedRadixSort:
         x.copy_(recv)
         if n_local > 1:
             be.sort(x, tmp, n_local, d)
+        be.finish()
+
+    def _all_gather_i64(self, a: np.ndarray, device) -> np.ndarray:
+        """[G, len(a)] int64: every rank's vector."""
+        import torch
+        src = torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64))
+        if self.host_staged:
+            out = [torch.zeros_like(src) for _ in range(self.world)]
+            self.dist.all_gather(out, src, group=self.group)
+            return torch.stack(out).numpy()
+        src = src.to(device)
+        out = [torch.zeros_like(src) for _ in range(self.world)]
+        self.dist.all_gather(out, src, group=self.group)
+        return torch.stack(out).cpu().numpy()
+
+    def _exchange(self, send, recv, send_counts, recv_counts, es: int):
+        import torch
+        if self.host_staged and send.is_cuda:
+            rc = torch.empty(recv.numel(), dtype=torch.uint8)
+            self.dist.all_to_all_single(rc, send.cpu(), output_split_sizes=(recv_counts * es).tolist(),
+                                        input_split_sizes=(send_counts * es).tolist(), group=self.group)
+            recv.copy_(rc)
+        else:
+            self.dist.all_to_all_single(recv, send, output_split_sizes=(recv_counts * es).tolist(),
+                                        input_split_sizes=(send_counts * es).tolist(), group=self.group)
+
+    def sort_exchange_first(self, x, d: RadixDigits, n_per_rank: Optional[List[int]] = None):
+        """Same contract as `sort`.  Partition by the top digit, exchange once, sort once."""
+        be = self.backend
+        es, G, me = d.elem_bytes, self.world, self.rank
+        n_local = x.numel() // es
+        if n_per_rank is None:
+            n_per_rank = self._gather_counts(n_local, x.device)
+        n_per_rank = np.asarray(n_per_rank, dtype=np.int64)
+        assert n_per_rank[me] == n_local
+        bounds = np.concatenate(([0], np.cumsum(n_per_rank)))
+        part = self._buf("part", n_local * es)
+        top = d.key_bytes - 1
+        # 1. one stable partition pass by the most significant digit (count + scatter, mod.rs:90-168)
+        hist = be.zeros_u64(256)
+        if n_local:
+            be.partition(x, part, n_local, d, top, hist)
+        H = self._all_gather_i64(hist.cpu().numpy() if hasattr(hist, "cpu") else np.asarray(hist), x.device)  # [G][256]
+        # 2. the buckets in global order (digit-major, rank-minor: mod.rs:110-120 with chunk == rank)
+        lstart = np.concatenate([np.zeros((G, 1), np.int64), np.cumsum(H, axis=1)], axis=1)  # [G][257]
+        tot = H.sum(axis=0)
+        gstart = np.concatenate(([0], np.cumsum(tot)))  # [257]
+        split = np.zeros((G, G + 1), dtype=np.int64)
+        split[:, G] = n_per_rank
+        inside = []  # (boundary, bucket) for boundaries strictly inside a bucket
+        for b in range(G - 1):
+            T = bounds[b + 1]
+            v = int(np.searchsorted(gstart[1:], T, side="right"))  # first bucket that ends above T
+            if v == 256:
+                split[:, b + 1] = n_per_rank
+            elif gstart[v] == T:
+                split[:, b + 1] = lstart[:, v]
+            else:
+                inside.append((b, v))
+        # boundary buckets: every rank sorts its piece (tmp piece in place, the old slice as scratch)
+        def piece(buf, v):
+            return buf[lstart[me, v] * es: lstart[me, v + 1] * es]
+        for v in sorted({v for _, v in inside}):
+            ln = int(lstart[me, v + 1] - lstart[me, v])
+            if ln > 1:
+                be.sort(piece(part, v), piece(x, v), ln, d)
+        if inside:
+            nb = len(inside)
+            rank_in = np.array([bounds[b + 1] - gstart[v] for b, v in inside], dtype=np.int64)
+            pre_lo = np.zeros(nb, dtype=np.uint64)
+            pre_hi = np.zeros(nb, dtype=np.uint64)
+            for i, (_, v) in enumerate(inside):
+                if top < 8:
+                    pre_lo[i] = np.uint64(v) << np.uint64(8 * top)
+                else:
+                    pre_hi[i] = np.uint64(v) << np.uint64(8 * (top - 8))
+            j256 = np.arange(256, dtype=np.uint64)
+            lens = [int(lstart[me, v + 1] - lstart[me, v]) for _, v in inside]
+            for digit in range(top - 1, -1, -1):
+                less = np.zeros((nb, 256), dtype=np.int64)
+                for i, (_, v) in enumerate(inside):
+                    lo = np.repeat(pre_lo[i], 256)
+                    hi = np.repeat(pre_hi[i], 256)
+                    if digit < 8:
+                        lo = lo | (j256 << np.uint64(8 * digit))
+                    else:
+                        hi = hi | (j256 << np.uint64(8 * (digit - 8)))
+                    less[i], _ = be.bounds(piece(part, v), lens[i], d, lo, hi)
+                gl = self._all_reduce_sum(less.reshape(-1), x.device).reshape(nb, 256)
+                j = ((gl <= rank_in[:, None]).sum(axis=1) - 1).astype(np.uint64)
+                if digit < 8:
+                    pre_lo |= j << np.uint64(8 * digit)
+                else:
+                    pre_hi |= j << np.uint64(8 * (digit - 8))
+            mine = np.zeros((2, nb), dtype=np.int64)
+            for i, (_, v) in enumerate(inside):
+                l, q = be.bounds(piece(part, v), lens[i], d, pre_lo[i:i + 1], pre_hi[i:i + 1])
+                mine[0, i], mine[1, i] = l[0], q[0]
+            M = self._all_gather_i64(mine.reshape(-1), x.device).reshape(G, 2, nb)
+            less, eq = M[:, 0, :], M[:, 1, :] - M[:, 0, :]
+            need = rank_in - less.sum(axis=0)  # elements equal to the boundary key that go below the cut
+            before = np.cumsum(eq, axis=0) - eq
+            take = np.clip(need[None, :] - before, 0, eq)  # ties: lower rank first (stability)
+            for i, (b, v) in enumerate(inside):
+                split[:, b + 1] = lstart[:, v] + less[:, i] + take[:, i]
+        send_counts = np.diff(split[me])
+        recv_counts = split[:, me + 1] - split[:, me]
+        assert send_counts.sum() == n_local and recv_counts.sum() == n_local, (send_counts, recv_counts)
+        # 3. the one exchange, straight back into the slice; 4. one local sort
+        self._exchange(part, x, send_counts, recv_counts, es)
+        if n_local > 1:
+            be.sort(x, part, n_local, d)
         be.finish()
 
     def sort(self, x, d: RadixDigits, n_per_rank: Optional[List[int]] = None):

@@ -33,7 +33,7 @@ def test_header_symbols_all_exported(lib):
 
 
 def test_version_and_strerror(lib):
-    assert lib.rsx_version() == 100
+    assert lib.rsx_version() == 200
     assert lib.rsx_strerror(0) == b"ok"
     for code in range(-7, 0):
         assert lib.rsx_strerror(code) not in (b"", b"unknown status")
@@ -67,6 +67,27 @@ def test_null_ctx_is_an_error_not_a_crash(lib):
     assert lib.rsx_sort_device(None, None, None, 10, ctypes.byref(lay), None) == -1
     assert lib.rsx_ctx_destroy(None) == -1
     assert lib.rsx_last_error(None) == b"null context"
+
+
+def test_options_validate_without_a_device(lib):
+    """rsx_ctx_set_option / rsx_ctx_get_info reject null contexts (no device needed for that)."""
+    out = ctypes.c_uint64(0)
+    assert lib.rsx_ctx_set_option(None, 1, 0) == -1
+    assert lib.rsx_ctx_get_info(None, 1, ctypes.byref(out)) == -1
+
+
+def test_no_stray_environment_switches():
+    """The production library reads no tuning switches from the environment: the ablation
+    bits exist only under -DRSX_TUNING, geometry knobs only through rsx_ctx_set_option."""
+    src = open(os.path.join(ROOT, "radix_sort_amd", "csrc", "rsx.hip")).read()
+    envs = set(re.findall(r'getenv\("([A-Z_]+)"\)', src))
+    assert envs <= {"RSX_VERBOSE", "RSX_DEBUG"}, envs
+    # RSX_DEBUG only inside the RSX_TUNING block
+    i = src.index('getenv("RSX_DEBUG")')
+    assert "#ifdef RSX_TUNING" in src[max(0, i - 300):i]
+    impl = open(os.path.join(ROOT, "radix_sort_amd", "csrc", "rsx_launch_impl.hpp")).read()
+    for m in re.finditer(r'getenv\("([A-Z_]+)"\)', impl):
+        assert "#ifdef RSX_TUNING" in impl[max(0, m.start() - 200):m.start()], m.group(1)
 
 
 def test_product_does_not_touch_the_oracle():

@@ -238,37 +238,30 @@ def test_more_than_2pow30_elements(rs, torch, ctx):
     _full_size(rs, torch, ctx, "(u8,[u8;7])", n, rs.GEN_CONSTANT, param=3.0)
 
 
-def test_64bit_status_words_single_region():
+def test_64bit_status_words_single_region(rs, torch):
     """Regions longer than 2^30 elements switch the look-back words to 64 bit.  With the default
-    8-16 regions that takes n > 2^33; RSX_REGIONS=1 (one chain over everything) reaches it at
-    n > 2^30.  Child process: the knob is read once per process."""
-    import subprocess
-    import sys
-    code = r'''
-import os, sys
-sys.path.insert(0, os.getcwd())
-import torch, radix_sort_amd as rs
-ctx = rs.default_context(0)
-n = (1 << 30) + (1 << 20) + 77
-for name, d, gen, param in (("u8", rs.PRIMITIVES["u8"], rs.GEN_UNIFORM, 0.0),
-                            ("(u8,[u8;7])", rs.RadixDigits(8, 0, 1, 0), rs.GEN_CONSTANT, 3.0)):
-    x = torch.empty(n * d.elem_bytes, dtype=torch.uint8, device="cuda")
-    tmp = torch.empty_like(x)
-    out = torch.zeros(3, dtype=torch.int64, device="cuda")
-    ctx.generate_device(x.data_ptr(), n, d, gen, 7, param)
-    ctx.verify_device(x.data_ptr(), n, d, out.data_ptr()); torch.cuda.synchronize()
-    before = out[1].item()
-    rs.radix_sort(x, digits=d, tmp=tmp); ctx.check()
-    ctx.verify_device(x.data_ptr(), n, d, out.data_ptr()); torch.cuda.synchronize()
-    assert out[0].item() == 0 and out[1].item() == before and out[2].item() == 0, (name, out.tolist())
-    del x, tmp
-print("STATUS64 OK")
-'''
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, RSX_REGIONS="1", RSX_DEBUG="0x200"),
-                         capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0 and "STATUS64 OK" in out.stdout, out.stdout + out.stderr[-3000:]
-    assert "regions=1" in out.stderr
+    8-16 regions that takes n > 2^33; one region (one chain over everything, RSX_OPT_MAX_REGIONS = 1)
+    reaches it at n > 2^30."""
+    c = rs.Context(torch.cuda.current_device())
+    c.set_option(rs.OPT_MAX_REGIONS, 1)
+    n = (1 << 30) + (1 << 20) + 77
+    for name, d, gen, param in (("u8", rs.PRIMITIVES["u8"], rs.GEN_UNIFORM, 0.0),
+                                ("(u8,[u8;7])", rs.RadixDigits(8, 0, 1, 0), rs.GEN_CONSTANT, 3.0)):
+        x = torch.empty(n * d.elem_bytes, dtype=torch.uint8, device="cuda")
+        tmp = torch.empty_like(x)
+        out = torch.zeros(3, dtype=torch.int64, device="cuda")
+        c.generate_device(x.data_ptr(), n, d, gen, 7, param)
+        c.verify_device(x.data_ptr(), n, d, out.data_ptr())
+        torch.cuda.synchronize()
+        before = out[1].item()
+        rs.radix_sort(x, digits=d, tmp=tmp, ctx=c)
+        c.check()
+        c.verify_device(x.data_ptr(), n, d, out.data_ptr())
+        torch.cuda.synchronize()
+        assert out[0].item() == 0 and out[1].item() == before and out[2].item() == 0, (name, out.tolist())
+        del x, tmp
+        torch.cuda.empty_cache()
+    c.close()
 
 
 def test_verify_detects_errors(rs, torch, ctx):
@@ -287,52 +280,52 @@ def test_verify_detects_errors(rs, torch, ctx):
     assert out[0].item() == 0 and out[2].item() == n - 1
 
 
-@pytest.mark.parametrize("switch,what", [("0x2000", "dynamic tile tickets instead of the static roll-call assignment"),
-                                         ("0x10000", "ranks by ballots only"),
-                                         ("0x20000", "ranks by returned LDS atomics whatever the skew"),
-                                         ("0x8000", "agent-scope status stores even on verified single-XCD chains"),
-                                         ("0x4000", "no XCD-major workgroup numbering"),
-                                         ("0x40000", "one-byte elements through the general pass instead of the counting path")])
-def test_alternative_kernel_paths_match(orc, switch, what):
-    """Every fallback / alternative path of the sweep kernel (selected by an RSX_DEBUG bit) must give
-    the same bytes as the default path.  Runs in a child process: the switches are read once per
-    context from the environment."""
-    import subprocess
-    import sys
-    code = r'''
-import os, sys
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
-import numpy as np, torch, util
-import radix_sort_amd as rs
-from oracle import oracle
-ctx = rs.default_context(0)
-for t, n, dist in (("u32", 3000001, "uniform"), ("(u64,u64)", 700001, "zipf"), ("f32", 1500000, "uniform"),
-                   ("u8", 5000000, "uniform"), ("i8", 3000001, "zipf"), ("(u8,[u8;7])", 2000003, "two"), ("(u32,u32)", 1000001, "step16"),
-                   ("(i16,u16)", 1234567, "equal"), ("u64", 2000001, "lowbyte"), ("(u32,[u8;8])", 500009, "zipf")):
-    d = rs.RadixDigits(*util.TYPES[t])
-    raw = util.make_input(t, n, dist, seed=31)
-    x = torch.from_numpy(raw.copy()).cuda()
-    rs.radix_sort(x, digits=d); ctx.check()
-    exp = oracle.sort_parallel(raw, oracle.Layout(*util.TYPES[t]), 8)
-    assert np.array_equal(x.cpu().numpy(), exp), (t, dist)
-print("PATH OK")
-'''
-    env = dict(os.environ, RSX_DEBUG=switch)
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "PATH OK" in out.stdout, what + "\n" + out.stdout + out.stderr
+ALT_PATHS = [("OPT_TILE_SCHEDULE", 1, "ticketed tiles instead of the static roll-call assignment"),
+             ("OPT_RANKING", 1, "ranks by ballots only"),
+             ("OPT_RANKING", 2, "ranks by returned LDS atomics whatever the skew"),
+             ("OPT_STATUS_SCOPE", 1, "agent-scope status stores even on verified single-XCD chains"),
+             ("OPT_XCD_MAJOR", 0, "no XCD-major workgroup numbering"),
+             ("OPT_BYTE_COUNTING", 0, "one-byte elements through the general pass instead of the counting path"),
+             ("OPT_MAX_REGIONS", 1, "one look-back chain over all tiles"),
+             ("OPT_MAX_REGIONS", 32, "32 look-back chains"),
+             ("OPT_HOT_LANES", 2, "every tile treated as skewed")]
 
 
-def test_lds_atomic_order_selftest_passes_on_gfx950():
-    """The sweep ranks by returned LDS atomics only if rsx_lds_order_kernel passed on this device;
-    on gfx950 it is expected to (otherwise the bench numbers are those of the ballot path)."""
-    import subprocess
-    import sys
-    code = "import torch, radix_sort_amd as rs; x = torch.arange(100000, 0, -1, dtype=torch.int32, device='cuda'); rs.radix_sort(x); torch.cuda.synchronize()"
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, RSX_DEBUG="0x200"),
-                         capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "self-test passed" in out.stderr, out.stdout + out.stderr
+@pytest.mark.parametrize("opt,value,what", ALT_PATHS)
+def test_alternative_kernel_paths_match(rs, torch, orc, opt, value, what):
+    """Every fallback / alternative path of the sweep kernel (rsx_ctx_set_option) must give the same
+    bytes as the oracle: these are the paths the library falls back to by itself when a device
+    self-test fails or the grid is not co-resident."""
+    c = rs.Context(torch.cuda.current_device())
+    c.set_option(getattr(rs, opt), value)
+    for t, n, dist in (("u32", 3000001, "uniform"), ("(u64,u64)", 700001, "zipf"), ("f32", 1500000, "uniform"),
+                       ("u8", 5000000, "uniform"), ("i8", 3000001, "zipf"), ("(u8,[u8;7])", 2000003, "two"),
+                       ("(u32,u32)", 1000001, "step16"), ("(i16,u16)", 1234567, "equal"), ("u64", 2000001, "lowbyte"),
+                       ("(u32,[u8;8])", 500009, "zipf")):
+        d = _digits(rs, t)
+        raw = util.make_input(t, n, dist, seed=31)
+        x = torch.from_numpy(raw.copy()).cuda()
+        rs.radix_sort(x, digits=d, ctx=c)
+        c.check()
+        exp = orc.sort_parallel(raw, orc.Layout(*util.TYPES[t]), 8)
+        assert np.array_equal(x.cpu().numpy(), exp), (what, t, dist)
+    c.close()
+
+
+def test_options_reject_bad_values(rs, torch):
+    c = rs.Context(torch.cuda.current_device())
+    for opt, bad in ((rs.OPT_TILE_SCHEDULE, 2), (rs.OPT_RANKING, 3), (rs.OPT_MAX_REGIONS, 33), (rs.OPT_HOT_LANES, 1), (99, 0)):
+        with pytest.raises(rs.RsxError):
+            c.set_option(opt, bad)
+    c.close()
+
+
+def test_device_self_tests_pass_on_gfx950(rs, torch, ctx):
+    """The sweep ranks by returned LDS atomics only if rsx_lds_order_kernel passed on this device, and
+    keeps single-XCD chains' status words in the L2 only if rsx_l2_probe_kernel did; on gfx950 both are
+    expected to (otherwise the bench numbers are those of the fallback paths)."""
+    assert ctx.get_info(rs.INFO_RANK_ATOMIC) == 1
+    assert ctx.get_info(rs.INFO_L2_LOCAL) == 1
 
 
 def test_many_sorts_one_context_and_graph_capture(rs, torch, ctx):
@@ -376,7 +369,9 @@ SHARD_SPLITS = [
 
 @pytest.mark.parametrize("t", ["u8", "u32", "i32", "f32", "u64", "f64", "i128", "(u64,u64)", "(u8,[u8;7])",
                                "(pay32+u32)", "(u32,[u8;8])"])
-def test_sharded_single_process(rs, torch, orc, t):
+@pytest.mark.parametrize("schedule", ["exchange_first", "sort_first"])
+def test_sharded_single_process(rs, torch, orc, t, schedule):
+    sched = rs.SHARD_EXCHANGE_FIRST if schedule == "exchange_first" else rs.SHARD_SORT_FIRST
     d = _digits(rs, t)
     lay = orc.Layout(*util.TYPES[t])
     es = util.TYPES[t][0]
@@ -389,7 +384,7 @@ def test_sharded_single_process(rs, torch, orc, t):
             offs = np.concatenate(([0], np.cumsum(split))) * es
             slices = [torch.from_numpy(flat[offs[g]:offs[g + 1]].copy()).cuda() for g in range(len(split))]
             ctxs = [rs.Context(torch.cuda.current_device()) for _ in split]
-            rs.radix_sort_sharded(slices, d, ctxs=ctxs)
+            rs.radix_sort_sharded(slices, d, ctxs=ctxs, schedule=sched)
             got = np.concatenate([s.cpu().numpy() for s in slices]) if n else np.zeros(0, np.uint8)
             assert np.array_equal(got, want.reshape(-1).view(np.uint8)), (t, split, dist)
             for c in ctxs:
@@ -434,3 +429,170 @@ def test_two_contexts_two_streams_concurrently(rs, torch, orc):
             assert np.array_equal(xs[i].cpu().numpy(), want[i]), (rep, i)
     for c in ctxs:
         c.close()
+
+
+
+# ---- BASELINE.json configs[3] and configs[4] at FULL size on the one GPU of the test box: one contiguous
+# ---- buffer viewed as 8 equal slices, rsx_sort_sharded with 8 same-device contexts (both schedules), checked
+# ---- (a) on device over the whole buffer (descents, multiset checksum, stability: slice boundaries included)
+# ---- and (b) bit for bit against rsx_sort_device of a copy of the same elements.
+def _equal_chunked(torch, a, b, chunk=1 << 30):
+    for off in range(0, a.numel(), chunk):
+        if not torch.equal(a[off:off + chunk], b[off:off + chunk]):
+            return False
+    return True
+
+
+def _full_config_sharded(rs, torch, t, logn, gen, param, seed):
+    d = _digits(rs, t)
+    n, G = 1 << logn, 8
+    es = d.elem_bytes
+    dev = torch.cuda.current_device()
+    c0 = rs.default_context(dev)
+    x = torch.empty(n * es, dtype=torch.uint8, device="cuda")
+    tmp = torch.empty_like(x)
+    ref = torch.empty_like(x)
+    out = torch.zeros(3, dtype=torch.int64, device="cuda")
+    per = n // G
+    ctxs = [rs.Context(dev) for _ in range(G)]
+    for g in range(G):  # payload = GLOBAL index (index_base), keys from one global counter stream
+        c0.generate_device(x.data_ptr() + g * per * es, per, d, gen, seed, param, g * per)
+    c0.verify_device(x.data_ptr(), n, d, out.data_ptr())
+    before = out.cpu().numpy().astype(np.uint64)
+    assert before[0] > 0
+    ref.copy_(x)
+    rs.radix_sort(ref, digits=d, tmp=tmp, ctx=c0)  # the single-GPU sort of the same 2^logn elements
+    c0.check()
+    c0.verify_device(ref.data_ptr(), n, d, out.data_ptr())
+    v = out.cpu().numpy().astype(np.uint64)
+    assert v[0] == 0 and v[1] == before[1] and v[2] == 0, v
+    keep = torch.empty_like(x)
+    keep.copy_(x)
+    for sched in (rs.SHARD_EXCHANGE_FIRST, rs.SHARD_SORT_FIRST):
+        x.copy_(keep)
+        slices = [x[g * per * es:(g + 1) * per * es] for g in range(G)]
+        tmps = [tmp[g * per * es:(g + 1) * per * es] for g in range(G)]
+        rs.radix_sort_sharded(slices, d, ctxs=ctxs, tmps=tmps, schedule=sched)
+        c0.verify_device(x.data_ptr(), n, d, out.data_ptr())
+        v = out.cpu().numpy().astype(np.uint64)
+        assert v[0] == 0, f"{v[0]} descents (schedule {sched})"
+        assert v[1] == before[1], "multiset checksum changed"
+        assert v[2] == 0, f"{v[2]} stability violations"
+        assert _equal_chunked(torch, x, ref), f"sharded result differs from the single-GPU sort (schedule {sched})"
+    for c in ctxs:
+        c.close()
+    del x, tmp, ref, keep
+    torch.cuda.empty_cache()
+
+
+def test_config4_4b_u32_sharded_full_size(rs, torch):
+    """configs[3]: 4B (2^32) u32 keys over 8 slices: 64-bit totals in the splitter search."""
+    _full_config_sharded(rs, torch, "u32", 32, rs.GEN_UNIFORM, 0.0, 0x5EED0004)
+
+
+def test_config5_1b_pairs_zipf_sharded_full_size(rs, torch):
+    """configs[4]: 1B (2^30) (u64 key, u64 payload = global index) Zipf pairs over 8 slices: skew + stability."""
+    _full_config_sharded(rs, torch, "(u64,u64)", 30, rs.GEN_ZIPF, 1.0, 0x5EED0005)
+
+
+def test_one_context_two_streams(rs, torch, orc):
+    """one context used from two streams -- the second stream's sort must wait (on the device)
+    for the first one's: they share the context's count matrices, tickets and status words."""
+    d = _digits(rs, "u32")
+    lay = orc.Layout(*util.TYPES["u32"])
+    n = 5_000_003
+    raws = [util.make_input("u32", n, "uniform", seed=700 + i) for i in range(2)]
+    want = [orc.sort_parallel(r, lay, 8) for r in raws]
+    c = rs.Context(torch.cuda.current_device())
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    xs = [torch.from_numpy(r.copy()).cuda() for r in raws]
+    tmps = [torch.empty_like(x) for x in xs]
+    for rep in range(5):
+        for i in range(2):
+            xs[i].copy_(torch.from_numpy(raws[i]).cuda())
+        torch.cuda.synchronize()
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                rs.radix_sort(xs[i], digits=d, tmp=tmps[i], ctx=c)
+        for i in range(2):
+            c.check(streams[i].cuda_stream)
+            assert np.array_equal(xs[i].cpu().numpy(), want[i]), (rep, i)
+    c.close()
+
+
+def test_unreserved_sort_under_capture_reports_workspace(rs, torch):
+    """A sort that would have to allocate while its stream is being captured returns RSX_ERR_WORKSPACE
+    instead of calling hipMalloc mid-capture."""
+    c = rs.Context(torch.cuda.current_device())
+    d = rs.PRIMITIVES["u32"]
+    n = 1 << 16
+    x = torch.randint(0, 2 ** 31 - 1, (n,), dtype=torch.int32, device="cuda")
+    tmp = torch.empty_like(x)
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    err = None
+    with torch.cuda.stream(s):
+        torch.cuda.synchronize()
+        g.capture_begin()
+        try:
+            c.sort_device(x.data_ptr(), tmp.data_ptr(), n, d, torch.cuda.current_stream().cuda_stream)
+        except rs.RsxError as e:
+            err = e
+        g.capture_end()
+    assert err is not None and err.status == -6, err
+    c.reserve(n, d)  # now it captures
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        g2.capture_begin()
+        c.sort_device(x.data_ptr(), tmp.data_ptr(), n, d, torch.cuda.current_stream().cuda_stream)
+        g2.capture_end()
+    g2.replay()
+    torch.cuda.synchronize()
+    c.check()
+    assert bool((x[1:] >= x[:-1]).all())
+    c.close()
+
+
+def test_two_streams_contention_costs_little(rs, torch):
+    """two sorts in flight on two streams (two contexts) may lose the start-up roll call
+    (the grids are not co-resident) -- that must cost a bounded wait once per sort, not a pass: the pair may
+    not take more than 1.5x the two sorts run one after the other."""
+    d = rs.PRIMITIVES["u32"]
+    n = 1 << 26
+    dev = torch.cuda.current_device()
+    ctxs = [rs.Context(dev) for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    src = [torch.empty(n * 4, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    xs = [torch.empty_like(a) for a in src]
+    tmps = [torch.empty_like(a) for a in src]
+    for i in range(2):
+        ctxs[i].reserve(n, d)
+        ctxs[i].generate_device(src[i].data_ptr(), n, d, rs.GEN_UNIFORM, 11 + i)
+    torch.cuda.synchronize()
+
+    def run(concurrent):
+        for i in range(2):
+            xs[i].copy_(src[i])
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for i in range(2):
+            st = streams[i] if concurrent else torch.cuda.current_stream()
+            st.wait_event(ev0)
+            with torch.cuda.stream(st):
+                rs.radix_sort(xs[i], digits=d, tmp=tmps[i], ctx=ctxs[i])
+        for i in range(2):
+            if concurrent:
+                torch.cuda.current_stream().wait_stream(streams[i])
+        ev1.record()
+        torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1)
+
+    for _ in range(2):
+        run(False), run(True)
+    serial = sorted(run(False) for _ in range(7))[3]
+    both = sorted(run(True) for _ in range(7))[3]
+    for c in ctxs:
+        c.check()
+        c.close()
+    assert both <= 1.5 * serial, (both, serial)

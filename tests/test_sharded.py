@@ -55,14 +55,6 @@ class OracleBackend:
         lay = self.orc.Layout(d.elem_bytes, d.key_offset, d.key_bytes, d.key_kind)
         x.numpy()[: n * d.elem_bytes] = self.orc.sort_parallel(x.numpy()[: n * d.elem_bytes].copy(), lay, 2)
 
-    def mapped_keys(self, x, n, d):
-        lay = self.orc.Layout(d.elem_bytes, d.key_offset, d.key_bytes, d.key_kind)
-        cols = self.orc.numpy_mapped_key_columns(x.numpy()[: n * d.elem_bytes], lay)
-        pad = np.zeros((n, 8), dtype=np.uint8)
-        pad[:, : d.key_bytes] = cols
-        u = pad.view("<u8").reshape(n)
-        return self.torch.from_numpy((u ^ np.uint64(1 << 63)).view(np.int64).copy())
-
     def bounds(self, x, n, d, q_lo, q_hi):
         lay = self.orc.Layout(d.elem_bytes, d.key_offset, d.key_bytes, d.key_kind)
         cols = self.orc.numpy_mapped_key_columns(x.numpy()[: n * d.elem_bytes], lay)
@@ -77,7 +69,7 @@ class OracleBackend:
         pass
 
 
-def _worker(rank, world, port, tname, dist_name, sizes, outdir, one_exchange=False):
+def _worker(rank, world, port, tname, dist_name, sizes, outdir, schedule="per-pass"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -95,7 +87,8 @@ def _worker(rank, world, port, tname, dist_name, sizes, outdir, one_exchange=Fal
         mine = full[off * d.elem_bytes:(off + sizes[rank]) * d.elem_bytes].copy()
         x = torch.from_numpy(mine)
         sorter = ShardedRadixSort(backend=OracleBackend())
-        (sorter.sort_one_exchange if one_exchange else sorter.sort)(x, d, n_per_rank=list(sizes))
+        {"per-pass": sorter.sort, "one": sorter.sort_one_exchange, "first": sorter.sort_exchange_first}[schedule](
+            x, d, n_per_rank=list(sizes))
         np.save(os.path.join(outdir, f"out{rank}.npy"), x.numpy())
     finally:
         dist.destroy_process_group()
@@ -125,12 +118,15 @@ def test_sharded_gloo_matches_single_sort(orc, tmp_path, world, tname, dist_name
     (3, "(u32,u32)", "two", (1000, 0, 2500)),   # heavy ties straddling both boundaries, an empty slice
     (3, "i16", "equal", (700, 900, 800)),       # every key equal: all splitting is by tie order
     (2, "f64", "uniform", (2048, 2049)),
-    (2, "u128", "uniform", (1500, 1500)),       # wide keys: falls back to the per-pass schedule
+    (2, "u128", "uniform", (1500, 1500)),       # wide keys: 128-bit splitters
+    (3, "(u8,u8)", "uniform", (900, 1100, 1000)),  # one-digit keys: the top digit is the whole key
+    (3, "u32", "sorted", (2000, 1, 3000)),
 ])
-def test_one_exchange_gloo_matches_single_sort(orc, tmp_path, world, tname, dist_name, sizes):
+@pytest.mark.parametrize("schedule", ["one", "first"])
+def test_one_exchange_gloo_matches_single_sort(orc, tmp_path, world, tname, dist_name, sizes, schedule):
     import torch.multiprocessing as mp
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, tname, dist_name, sizes, str(tmp_path), True), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, tname, dist_name, sizes, str(tmp_path), schedule), nprocs=world, join=True)
     got = np.concatenate([np.load(tmp_path / f"out{r}.npy") for r in range(world)])
     lay = orc.Layout(*util.TYPES[tname])
     full = util.make_input(tname, sum(sizes), dist_name, seed=77)
@@ -158,11 +154,15 @@ def test_exchange_plan_properties():
             for so, do, ln in segs:
                 cover[do:do + ln] += 1
             assert (cover == 1).all()
-            assert segs[:, 0].tolist() == sorted(segs[:, 0].tolist()) or True
+            # pieces sit in the receive buffer without gaps or overlap as well
+            src_cover = np.zeros(n_per[r], dtype=np.int32)
+            for so, do, ln in segs:
+                src_cover[so:so + ln] += 1
+            assert (src_cover == 1).all()
 
 
 # ---- GPU: the real HIP local steps under the same exchange, 2 ranks sharing one MI355X ----------
-def _gpu_worker(rank, world, port, tname, dist_name, sizes, outdir, one_exchange=False):
+def _gpu_worker(rank, world, port, tname, dist_name, sizes, outdir, schedule="per-pass"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -179,7 +179,8 @@ def _gpu_worker(rank, world, port, tname, dist_name, sizes, outdir, one_exchange
         off = sum(sizes[:rank])
         x = torch.from_numpy(full[off * d.elem_bytes:(off + sizes[rank]) * d.elem_bytes].copy()).cuda()
         sorter = ShardedRadixSort()  # product backend: HIP through the C-ABI
-        (sorter.sort_one_exchange if one_exchange else sorter.sort)(x, d, n_per_rank=list(sizes))
+        {"per-pass": sorter.sort, "one": sorter.sort_one_exchange, "first": sorter.sort_exchange_first}[schedule](
+            x, d, n_per_rank=list(sizes))
         np.save(os.path.join(outdir, f"out{rank}.npy"), x.cpu().numpy())
     finally:
         dist.destroy_process_group()
@@ -209,10 +210,11 @@ def test_sharded_hip_two_ranks_one_gpu(orc, tmp_path, tname, dist_name, sizes):
     ("(u32,u32)", "two", (200000, 123457)),
     ("i16", "equal", (65536, 70000)),
 ])
-def test_one_exchange_hip_two_ranks_one_gpu(orc, tmp_path, tname, dist_name, sizes):
+@pytest.mark.parametrize("schedule", ["one", "first"])
+def test_one_exchange_hip_two_ranks_one_gpu(orc, tmp_path, tname, dist_name, sizes, schedule):
     import torch.multiprocessing as mp
     port = _free_port()
-    mp.spawn(_gpu_worker, args=(2, port, tname, dist_name, sizes, str(tmp_path), True), nprocs=2, join=True)
+    mp.spawn(_gpu_worker, args=(2, port, tname, dist_name, sizes, str(tmp_path), schedule), nprocs=2, join=True)
     got = np.concatenate([np.load(tmp_path / f"out{r}.npy") for r in range(2)])
     lay = orc.Layout(*util.TYPES[tname])
     full = util.make_input(tname, sum(sizes), dist_name, seed=78)

@@ -5,6 +5,6 @@ for round in 1 2; do
 for vv in $1; do
   v=${vv%%@*}; dbg=0; [[ "$vv" == *@* ]] && dbg=${vv#*@}
   echo "== $vv (round $round)"
-  RSX_DEBUG=$dbg RSX_LIBRARY=/root/repo/radix_sort_amd/lib/v/$v.so python tools/perf.py $2 2>&1 | tail -n $(echo $2 | wc -w)
+  RSX_DEBUG=$dbg RSX_LIBRARY=$(dirname $0)/../radix_sort_amd/lib/v/$v.so python tools/perf.py $2 2>&1 | tail -n $(echo $2 | wc -w)
 done
 done

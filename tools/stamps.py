@@ -16,7 +16,8 @@ for it in range(2):
     L.rsx_debug_counters(ctx._h, out, 1)
     rs.radix_sort(x, digits=d, tmp=tmp)
     L.rsx_debug_counters(ctx._h, out, 1)
-    ntile = d.key_bytes * n / (512*(16 if d.elem_bytes<=4 else 64//d.elem_bytes))
+    kpt = int(os.environ.get('KPT', {4: 28, 8: 12, 16: 5}.get(d.elem_bytes, 28)))
+    ntile = d.key_bytes * n / (512 * kpt)
     for w in range(8):
         o = out[w*8:(w+1)*8]
         tot = sum(o[k] for k in range(7))
