@@ -93,8 +93,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 def build_variant(name: str, only_es, flags, verbose: bool = False) -> str:
     """lib/v/NAME.so: the main build's objects with the named element sizes recompiled under `flags`
-    (load it with RSX_LIBRARY=...).  Flags that change the host object's view (rsx_internal.hpp
-    knobs such as -DRSX_KPT4) are safe: they are read only by the per-size units."""
+    (load it with RSX_LIBRARY=...).  Flags that the host unit reads too (tile geometry: -DRSX_KPT*, -DRSX_WG*)
+    need `--es all`, which recompiles every unit."""
     if stale():
         build(force=True, verbose=verbose)
     vdir = os.path.join(LIBDIR, "v")

@@ -438,6 +438,22 @@ int rsx_ctx_profile(rsx_ctx* ctx, int enable) try {
     return RSX_ERR_NOMEM;
 }
 
+// Durations (ms) of the sweep launches read by rsx_ctx_profile_read so far, in launch order (diagnostics;
+// not part of include/rsx.h).  Returns how many were written; clears the list.
+int rsx_debug_sweep_times(rsx_ctx* ctx, float* out, int max) try {
+    if (!ctx || !out) return RSX_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    int n = 0;
+    for (float t : ctx->prof_each) {
+        if (n >= max) break;
+        out[n++] = t;
+    }
+    ctx->prof_each.clear();
+    return n;
+} catch (...) {
+    return RSX_ERR_NOMEM;
+}
+
 int rsx_ctx_profile_read(rsx_ctx* ctx, double* ms, uint64_t* launches) try {
     if (!ctx || !ms || !launches) return RSX_ERR_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -449,6 +465,7 @@ int rsx_ctx_profile_read(rsx_ctx* ctx, double* ms, uint64_t* launches) try {
             RSX_HIP(hipEventElapsedTime(&t, e.first, e.second));
             ctx->prof_ms[k] += t;
             ctx->prof_n[k] += 1;
+            if (k == RSX_PROF_SWEEP && ctx->prof_each.size() < 4096) ctx->prof_each.push_back(t);
             ctx->prof_free.push_back(e);
         }
         ctx->prof_pending[k].clear();

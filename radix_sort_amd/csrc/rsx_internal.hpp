@@ -93,6 +93,7 @@ struct rsx_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_free;
     double prof_ms[RSX_PROF_KINDS] = {0, 0, 0, 0};
     uint64_t prof_n[RSX_PROF_KINDS] = {0, 0, 0, 0};
+    std::vector<float> prof_each;  // per-launch sweep times (rsx_debug_sweep_times)
 };
 
 namespace rsxh {
