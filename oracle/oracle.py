@@ -63,6 +63,10 @@ def lib():
         L.orc_rand64.restype = ctypes.c_uint64
         L.orc_generate.argtypes = [vp, sz, lp, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]
         L.orc_generate.restype = ctypes.c_int
+        L.orc_radix_sort_variant.argtypes = [vp, sz, lp, ctypes.c_int, ctypes.c_int]
+        L.orc_radix_sort_variant.restype = ctypes.c_int
+        L.orc_counting_sort.argtypes = [vp, sz]
+        L.orc_counting_sort.restype = ctypes.c_int
         _LIB = L
     return _LIB
 
@@ -96,6 +100,28 @@ def sort_parallel_inplace(raw: np.ndarray, layout: Layout, threads: int) -> None
     n = raw.size // layout.elem_bytes
     rc = lib().orc_radix_sort(raw.ctypes.data, n, ctypes.byref(layout), threads)
     assert rc == 0
+
+
+def sort_variant(raw: np.ndarray, layout: Layout, threads: int, variant: int) -> np.ndarray:
+    """The reference's optimisation ladder radix_sort0..5 (mod.rs:178-571): variant 0..5, same output each."""
+    out = np.array(raw, dtype=np.uint8, copy=True)
+    n = out.size // layout.elem_bytes
+    rc = lib().orc_radix_sort_variant(out.ctypes.data, n, ctypes.byref(layout), threads, variant)
+    assert rc == 0
+    return out
+
+
+def sort_variant_inplace(raw: np.ndarray, layout: Layout, threads: int, variant: int) -> None:
+    n = raw.size // layout.elem_bytes
+    rc = lib().orc_radix_sort_variant(raw.ctypes.data, n, ctypes.byref(layout), threads, variant)
+    assert rc == 0
+
+
+def counting_sort(raw: np.ndarray) -> np.ndarray:
+    """counting_sort of mod.rs:40-59 (u8 only)."""
+    out = np.array(raw, dtype=np.uint8, copy=True)
+    assert lib().orc_counting_sort(out.ctypes.data, out.size) == 0
+    return out
 
 
 def partition_pass(raw: np.ndarray, layout: Layout, digit: int):

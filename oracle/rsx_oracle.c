@@ -378,3 +378,173 @@ int orc_generate(void *data, size_t n, const orc_layout *L, int gen, uint64_t se
     }
     return 0;
 }
+
+/* ---- the reference's optimisation ladder (mod.rs:40-59,178-571) ------------------------------
+ * the experimental variants the reference keeps beside its production sort, restated
+ * as CPU ablation baselines (tools/cpu_ladder.py times them).  All give the same bytes as
+ * orc_radix_sort -- they differ in threading, in how the scratch buffer is made and in write
+ * buffering:
+ *   0  radix_sort0  single thread, zero-initialised scratch                     mod.rs:183-212
+ *   1  radix_sort1  one thread per digit counts the whole array (a digit's histogram does not
+ *                   depend on the order), then serial scatter passes           mod.rs:215-259
+ *   2  radix_sort2  chunk per thread: parallel count, digit-major/chunk-minor scan, parallel
+ *                   unbuffered scatter; zero-initialised scratch               mod.rs:262-335
+ *   3  radix_sort3  = 2 with an uninitialised scratch touched one byte per page mod.rs:338-424
+ *   4  radix_sort4  = 3 on a work pool with two chunks per worker (rayon)      mod.rs:427-492
+ *   5  radix_sort5  = 3 + 96-element write buffers: the production sort        mod.rs:495-570
+ *   counting_sort   u8 only: count, scan, place, copy back                     mod.rs:40-59 */
+static inline __attribute__((always_inline)) void orc_scatter_plain_body(orc_job *j, const size_t s) { /* mod.rs:318-327 */
+    for (size_t i = j->begin; i < j->end; ++i) {
+        const uint8_t *e = j->src + i * s;
+        uint32_t v = orc_digit(e, j->L, j->digit);
+        memcpy(j->dst + j->hist[v] * s, e, s);
+        j->hist[v]++;
+    }
+}
+static void *orc_scatter_plain_worker(void *arg) {
+    orc_job *j = (orc_job *)arg;
+    ORC_BY_SIZE(orc_scatter_plain_body, j)
+    return NULL;
+}
+
+typedef struct { /* a pool worker: pulls job indices until none are left (variant 4) */
+    orc_job *jobs;
+    size_t njobs;
+    size_t *next; /* shared cursor */
+    void *(*fn)(void *);
+} orc_pool_arg;
+static void *orc_pool_worker(void *arg) {
+    orc_pool_arg *p = (orc_pool_arg *)arg;
+    for (;;) {
+        size_t k = __atomic_fetch_add(p->next, 1, __ATOMIC_RELAXED);
+        if (k >= p->njobs) return NULL;
+        p->fn(&p->jobs[k]);
+    }
+}
+/* runs fn over the jobs: one thread per job, or `pool` (> 0) threads pulling jobs */
+static int orc_run(orc_job *jobs, size_t njobs, void *(*fn)(void *), pthread_t *tids, int pool) {
+    if (njobs == 1) {
+        fn(&jobs[0]);
+        return 0;
+    }
+    if (pool > 0) {
+        size_t next = 0;
+        orc_pool_arg pa = {jobs, njobs, &next, fn};
+        int started = 0;
+        for (int t = 0; t < pool; ++t, ++started)
+            if (pthread_create(&tids[t], NULL, orc_pool_worker, &pa)) break;
+        for (int t = 0; t < started; ++t) pthread_join(tids[t], NULL);
+        return started == pool ? 0 : -1;
+    }
+    for (size_t c = 0; c < njobs; ++c)
+        if (pthread_create(&tids[c], NULL, fn, &jobs[c])) {
+            for (size_t k = 0; k < c; ++k) pthread_join(tids[k], NULL);
+            return -1;
+        }
+    for (size_t c = 0; c < njobs; ++c) pthread_join(tids[c], NULL);
+    return 0;
+}
+
+int orc_radix_sort_variant(void *data, size_t n, const orc_layout *L, int threads, int variant) {
+    const size_t s = L->elem_bytes;
+    if (n == 0) return 0;
+    if (variant == 0) return orc_radix_sort0(data, n, L);
+    if (variant == 5) return orc_radix_sort(data, n, L, threads);
+    if (variant < 1 || variant > 4) return -1;
+    if (threads < 1) threads = 1;
+    const uint32_t D = L->key_bytes;
+    uint8_t *self = (uint8_t *)data;
+    int rc = 0;
+    if (variant == 1) {
+        /* one job per digit over the whole (unsorted) array: counts, then each digit's exclusive scan */
+        uint8_t *temp = (uint8_t *)calloc(n, s); /* vec![T::default(); len] */
+        orc_job *jobs = (orc_job *)calloc(D, sizeof(orc_job));
+        pthread_t *tids = (pthread_t *)calloc(D, sizeof(pthread_t));
+        if (!temp || !jobs || !tids) rc = -1;
+        if (!rc) {
+            for (uint32_t d = 0; d < D; ++d) {
+                jobs[d].src = self;
+                jobs[d].begin = 0;
+                jobs[d].end = n;
+                jobs[d].L = L;
+                jobs[d].digit = d;
+            }
+            rc = orc_run(jobs, D, orc_count_worker, tids, 0);
+        }
+        for (uint32_t d = 0; d < D && !rc; ++d) {
+            size_t start = 0;
+            for (int v = 0; v < 256; ++v) {
+                size_t c = jobs[d].hist[v];
+                jobs[d].hist[v] = start;
+                start += c;
+            }
+            jobs[d].src = (d % 2 == 0) ? self : temp;
+            jobs[d].dst = (d % 2 == 0) ? temp : self;
+            orc_scatter_plain_worker(&jobs[d]); /* serial scatter (mod.rs:246-254) */
+        }
+        if (!rc && D % 2 == 1) memcpy(self, temp, n * s);
+        free(tids);
+        free(jobs);
+        free(temp);
+        return rc;
+    }
+    /* variants 2-4: chunked */
+    const size_t parts = variant == 4 ? (size_t)threads * 2 : (size_t)threads; /* CHUNK_MULTIPLIER, mod.rs:430 */
+    const size_t per = (n + parts - 1) / parts;
+    const size_t chunks = (n + per - 1) / per;
+    uint8_t *temp = variant == 2 ? (uint8_t *)calloc(n, s) : (uint8_t *)malloc(n * s);
+    orc_job *jobs = (orc_job *)calloc(chunks, sizeof(orc_job));
+    pthread_t *tids = (pthread_t *)calloc(chunks > (size_t)threads ? chunks : (size_t)threads, sizeof(pthread_t));
+    if (!temp || !jobs || !tids) {
+        rc = -1;
+        goto out;
+    }
+    if (variant != 2)
+        for (size_t b = 0; b < n * s; b += ORC_PAGE_SIZE) temp[b] = 0; /* page touch (mod.rs:346-357) */
+    for (size_t c = 0; c < chunks; ++c) {
+        jobs[c].begin = c * per;
+        jobs[c].end = (c + 1) * per < n ? (c + 1) * per : n;
+        jobs[c].L = L;
+    }
+    for (uint32_t d = 0; d < D && !rc; ++d) {
+        for (size_t c = 0; c < chunks; ++c) {
+            jobs[c].src = (d % 2 == 0) ? self : temp;
+            jobs[c].dst = (d % 2 == 0) ? temp : self;
+            jobs[c].digit = d;
+        }
+        rc = orc_run(jobs, chunks, orc_count_worker, tids, variant == 4 ? threads : 0);
+        if (rc) break;
+        size_t prefix = 0;
+        for (int v = 0; v < 256; ++v)
+            for (size_t c = 0; c < chunks; ++c) {
+                size_t cnt = jobs[c].hist[v];
+                jobs[c].hist[v] = prefix;
+                prefix += cnt;
+            }
+        rc = orc_run(jobs, chunks, orc_scatter_plain_worker, tids, variant == 4 ? threads : 0);
+    }
+    if (!rc && D % 2 == 1) memcpy(self, temp, n * s);
+out:
+    free(tids);
+    free(jobs);
+    free(temp);
+    return rc;
+}
+
+/* mod.rs:40-59: counting sort of bytes */
+int orc_counting_sort(uint8_t *data, size_t n) {
+    uint8_t *temp = (uint8_t *)calloc(n ? n : 1, 1);
+    if (!temp) return -1;
+    size_t hist[256] = {0};
+    for (size_t i = 0; i < n; ++i) hist[data[i]]++;
+    size_t start = 0;
+    for (int v = 0; v < 256; ++v) {
+        size_t c = hist[v];
+        hist[v] = start;
+        start += c;
+    }
+    for (size_t i = 0; i < n; ++i) temp[hist[data[i]]++] = data[i];
+    memcpy(data, temp, n);
+    free(temp);
+    return 0;
+}

@@ -404,14 +404,17 @@ constexpr uint32_t SWEEP_OPT_AGENT_STATUS = 4u;  // agent-scope status stores on
 #ifndef RSX_LDS_SWIZZLE
 #define RSX_LDS_SWIZZLE 1
 #endif
-#ifndef RSX_LB_WIDE
-#define RSX_LB_WIDE 1
-#endif
 #ifndef RSX_DPP_SCAN
 #define RSX_DPP_SCAN 2  // 0 off, 1 on, 2 = where measured faster (elements of <= 4 bytes)
 #endif
 #ifndef RSX_ROLLCALL_TICKS
 #define RSX_ROLLCALL_TICKS 40000  // s_memtime ticks (shader cycles) a workgroup waits for the full grid
+#endif
+#ifndef RSX_LB_OVERLAP
+#define RSX_LB_OVERLAP 0  // 1: walk the look-back chain beside the LDS reorder (measured slower, see below)
+#endif
+#ifndef RSX_LB_EVERY
+#define RSX_LB_EVERY 4    // elements a wave reorders between two look-back steps
 #endif
 #ifndef RSX_PREFETCH_ALL
 #define RSX_PREFETCH_ALL 3  // 0 off, 1 before/after the look-back, 2 behind it, 3 = 2 where measured faster (>= 12-byte elements)
@@ -902,11 +905,40 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         // the status words of the NEXT pass live in a second array; each tile zeroes its row there,
         // which spares a memset launch per pass
         if (a.status_clean != nullptr && tid < RADIX) static_cast<S*>(a.status_clean)[stat_row + tid] = 0;
-        // first hop of the look-back, requested now and looked at after the LDS reorder: an
-        // aggregate or inclusive word stays true however old it is; an empty one is read again
-        S early = 0;
-        if (EARLY_HOP && tid < RADIX && kt > 0)
-            early = __hip_atomic_load(&status[stat_row - RADIX + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- decoupled look-back inside the region's chain: state of digit `tid` (waves 0..3) ------
+        // The walk back over the chain's earlier tiles is a series of dependent round trips (~500 cycles
+        // each from the chain's L2).  Its first hop is requested now and looked at after the LDS reorder
+        // (an aggregate or inclusive word stays true however old it is; an empty one is read again); the
+        // rest of the walk follows the reorder.  RSX_LB_OVERLAP = 1 takes further steps of the walk BESIDE
+        // the reorder (one after every RSX_LB_EVERY elements a wave has put into LDS) and publishes the
+        // inclusive prefix the moment the walk ends: measured slower on 4-byte keys (256M u32: 0.468 ->
+        // 0.485-0.498 ms per pass at every step spacing tried) and no different on 8- and 16-byte elements --
+        // the waves that walk stall inside the reorder on each word, and the other four wait for them at
+        // the barrier either way.
+        S lb_pend = 0;         // the word of the hop in flight
+        S lb_excl = 0;         // sum of the predecessors' counts so far (region-relative: fits S)
+        uint32_t lb_left = 0;  // predecessors not yet summed (tiles kt-1 .. 0 of the chain); 0 = walk finished
+        if ((EARLY_HOP || RSX_LB_OVERLAP) && tid < RADIX && kt > 0) {
+            lb_left = kt;
+            lb_pend = __hip_atomic_load(&status[stat_row - RADIX + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // one step of the walk: take the word in flight, request the next.  false = that word was still empty.
+        auto lb_step = [&]() __attribute__((always_inline)) -> bool {
+            if (lb_left == 0) return true;
+            const uint32_t f = (uint32_t)(lb_pend >> Status<S>::SHIFT);
+            if (f != 0) {
+                lb_excl += (S)(lb_pend & Status<S>::MASK);
+                lb_left = f == 2 ? 0u : lb_left - 1u;
+            }
+            if (lb_left == 0) {
+                const uint32_t real = (tid == 255) ? tcount - pad : tcount;
+                publish(&status[stat_row + tid], ((S)2 << Status<S>::SHIFT) | (S)((lb_excl + (S)real) & Status<S>::MASK));
+            } else {
+                lb_pend = __hip_atomic_load(&status[stat_row - (uint64_t)(kt - lb_left + 1u) * RADIX + tid], __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return f != 0;
+        };
         // exclusive scan of tcount over the 256 digits -> start of each digit's run in the tile
         uint32_t incl = tcount;
         if (tid < RADIX) {
@@ -940,6 +972,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
             // otherwise put all 64 lanes of a wave on one bank
             const uint32_t pos = my_hist[d] + ((pk[j / 2] >> (16 * (j & 1))) & 0xFFFFu);
             s_elems[RSX_LDS_SWIZZLE ? (pos ^ ((pos >> 5) & 31u)) : pos] = e[j];
+            if (RSX_LB_OVERLAP && j % RSX_LB_EVERY == RSX_LB_EVERY - 1 && j + 1 < KPT && tid < RADIX) lb_step();  // (wave-uniform)
         }
         __syncthreads();  // s_whist is dead from here: s_base takes its place
         RSX_STAMP(4);
@@ -957,67 +990,24 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         preloaded = prefetch;
         if (prefetch && RSX_PREFETCH_ALL == 1 && tid >= RADIX) issue_next();
 
-        // ---- decoupled look-back inside the region's chain -----------------------
+        // ---- what is left of the look-back ------------------------------------------------------
         if (tid < RADIX) {
-            uint64_t excl = 0;
-            if (kt > 0) {
-                // LBW predecessors per round trip: the loads are independent, so one round trip (~500
-                // cycles from the chain's L2) can cover several tiles of the walk back
-                constexpr uint32_t LBW = RSX_LB_WIDE;
-                uint64_t row = stat_row - RADIX;  // predecessor in the chain
-                uint32_t left = kt;               // predecessors not yet summed (tiles kt-1 .. 0 of the chain)
-                uint32_t spins = 0, hops = 0;
-                bool done = false;
-                while (!done) {
-                    ++hops;
-                    S s[LBW];
-                    if (EARLY_HOP && LBW == 1 && hops == 1 && (early >> Status<S>::SHIFT) != 0) {
-                        s[0] = early;
-                    } else {
-#pragma unroll
-                        for (uint32_t i = 0; i < LBW; ++i)
-                            s[i] = (i == 0 || i < left)
-                                       ? __hip_atomic_load(&status[row - (uint64_t)i * RADIX + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                       : (S)0;
+            if (!(EARLY_HOP || RSX_LB_OVERLAP) && kt > 0) {  // nothing requested yet
+                lb_left = kt;
+                lb_pend = __hip_atomic_load(&status[stat_row - RADIX + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            uint32_t spins = 0;
+            while (lb_left != 0) {
+                if (!lb_step()) {
+                    if (++spins > (1u << 22)) {  // bounded: never hang the device
+                        __hip_atomic_store(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
                     }
-                    uint32_t used = 0;
-                    bool open = true;  // still summing this batch
-#pragma unroll
-                    for (uint32_t i = 0; i < LBW; ++i) {
-                        const uint32_t f = (uint32_t)(s[i] >> Status<S>::SHIFT);
-                        if (open && f != 0) {
-                            excl += (uint64_t)(s[i] & Status<S>::MASK);
-                            ++used;
-                            if (f == 2) {
-                                done = true;
-                                open = false;
-                            }
-                        } else {
-                            open = false;
-                        }
-                    }
-                    if (done) break;
-                    row -= (uint64_t)used * RADIX;
-                    left -= used;
-                    if (used == 0) {
-                        if (++spins > (1u << 22)) {  // bounded: never hang the device
-                            __hip_atomic_store(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
+                    __builtin_amdgcn_s_sleep(1);
                 }
-                if (RSX_DBG(a, 0x100u) && tid == 0) {  // diagnostics: hop / stall statistics of digit 0
-                    atomicAdd(&a.dbg_cnt[0], 1ull);
-                    atomicAdd(&a.dbg_cnt[1], (unsigned long long)hops);
-                    atomicAdd(&a.dbg_cnt[2], (unsigned long long)spins);
-                    atomicMax(&a.dbg_cnt[4], (unsigned long long)hops);
-                }
-                const uint32_t real = (tid == 255) ? tcount - pad : tcount;
-                publish(&status[stat_row + tid], ((S)2 << Status<S>::SHIFT) | (S)((excl + real) & (uint64_t)Status<S>::MASK));
             }
             // element index of LDS slot 0 if it belonged to this digit's run (wrap-safe in u64)
-            s_base[tid] = rbase + excl - (uint64_t)tstart;
+            s_base[tid] = rbase + (uint64_t)lb_excl - (uint64_t)tstart;
             if (prefetch && RSX_PREFETCH_ALL == 1) issue_next();
         }
         __syncthreads();

@@ -4,9 +4,14 @@
 //!
 //! `get_digit` is arbitrary user code, so the device cannot run it; device dispatch keys off
 //! an additional associated const, `RSX_KEY`, which the 14 built-in key kinds set and the tuple
-//! impl forwards.  A type that leaves it `None` keeps the reference's own CPU body (the
-//! maintainer pastes the existing `mod.rs:62-175` into `cpu_radix_sort`), so nothing the
-//! reference accepts stops compiling.
+//! impl forwards.  A type that leaves it `None`, or whose size has no device kernel, takes the CPU
+//! path `cpu_radix_sort` (the reference's algorithm, restated below), so everything the reference
+//! accepts still compiles AND sorts.
+//!
+//! STATUS: this crate has never been compiled -- the build image has no cargo/rustc -- so it is
+//! text, not a tested artefact; every C call it makes is exercised by the C++ mirror
+//! (`radix_sort_amd/cxx/radix_sort.hpp`) and the ctypes harness.  Parity with the reference's own
+//! binary is unpinned for the same reason.
 #![allow(clippy::missing_safety_doc)]
 use core::ffi::{c_char, c_int, c_void};
 
@@ -142,8 +147,103 @@ impl<T: RadixDigits> RadixSort<T> for [T] {
     }
 }
 
-/// The reference's own body (`src/radix_sort/mod.rs:62-175`) goes here unchanged when this
-/// shim is merged; it serves user key types with a custom `get_digit` and odd element sizes.
-fn cpu_radix_sort<T: RadixDigits>(_data: &mut [T]) {
-    unimplemented!("paste the existing mod.rs:62-175 body here when integrating")
+/// CPU path, for the element types the device library has no kernel for: a user key type with its own
+/// `get_digit` (`RSX_KEY == None`) or an element size outside {1, 2, 4, 8, 12, 16, 24, 32}.  Same
+/// algorithm as the reference's body (`src/radix_sort/mod.rs:62-175`), restated: one chunk per hardware
+/// thread, per-chunk digit counts, digit-major / chunk-minor running sum, scatter through 96-element
+/// staging runs per digit, ping-pong between the slice and a scratch buffer, copy-back after an odd
+/// number of passes.  Elements are moved bitwise (no `Copy` bound), as in `mod.rs:133-140`.
+/// Same output as the device path on the types both accept: a stable sort by mapped key has one answer.
+fn cpu_radix_sort<T: RadixDigits>(data: &mut [T]) {
+    use core::mem::MaybeUninit;
+    use core::ptr::copy_nonoverlapping;
+    const STAGE: usize = 96; // mod.rs:64
+
+    struct Raw<T>(*mut T);
+    impl<T> Clone for Raw<T> {
+        fn clone(&self) -> Self {
+            Raw(self.0)
+        }
+    }
+    impl<T> Copy for Raw<T> {}
+    // the chunks write disjoint ranges of the destination (their cursors come from one running sum)
+    unsafe impl<T> Send for Raw<T> {}
+    unsafe impl<T> Sync for Raw<T> {}
+
+    let n = data.len();
+    let threads = std::thread::available_parallelism().map(|v| v.get()).unwrap_or(1);
+    let per_chunk = (n + threads - 1) / threads; // n >= 2 here
+    let mut scratch: Vec<MaybeUninit<T>> = Vec::with_capacity(n);
+    // SAFETY: MaybeUninit needs no initialisation; every slot is written by pass 0 before it is read.
+    unsafe { scratch.set_len(n) };
+    let slice_ptr = data.as_mut_ptr();
+    let scratch_ptr = scratch.as_mut_ptr() as *mut T;
+
+    for digit in 0..T::NUMBER_OF_DIGITS {
+        let (src_ptr, dst_ptr) = if digit % 2 == 0 { (slice_ptr, scratch_ptr) } else { (scratch_ptr, slice_ptr) };
+        // SAFETY: both buffers hold n initialised elements whenever they are the source of a pass.
+        let src: &[T] = unsafe { core::slice::from_raw_parts(src_ptr as *const T, n) };
+        // count (mod.rs:90-109)
+        let mut cursors: Vec<[usize; 256]> = std::thread::scope(|scope| {
+            let workers: Vec<_> = src
+                .chunks(per_chunk)
+                .map(|chunk| {
+                    scope.spawn(move || {
+                        let mut counts = [0usize; 256];
+                        for element in chunk {
+                            counts[element.get_digit(digit) as usize] += 1;
+                        }
+                        counts
+                    })
+                })
+                .collect();
+            workers.into_iter().map(|w| w.join().expect("count worker panicked")).collect()
+        });
+        // prefix: digit-major, chunk-minor (mod.rs:110-120) -- this order is what makes the pass stable
+        let mut running = 0usize;
+        for value in 0..256 {
+            for chunk_counts in cursors.iter_mut() {
+                let count = chunk_counts[value];
+                chunk_counts[value] = running;
+                running += count;
+            }
+        }
+        // scatter through staging runs (mod.rs:121-168)
+        let dst = Raw(dst_ptr);
+        std::thread::scope(|scope| {
+            for (chunk, mut cursor) in src.chunks(per_chunk).zip(cursors.into_iter()) {
+                scope.spawn(move || {
+                    let dst = dst;
+                    let mut staging: Vec<MaybeUninit<T>> = Vec::with_capacity(256 * STAGE);
+                    // SAFETY: MaybeUninit; a slot is read only after it was filled.
+                    unsafe { staging.set_len(256 * STAGE) };
+                    let stage = staging.as_mut_ptr() as *mut T;
+                    let mut filled = [0usize; 256];
+                    for element in chunk {
+                        let value = element.get_digit(digit) as usize;
+                        // SAFETY: bitwise moves between disjoint buffers; indices are in range by the counts.
+                        unsafe {
+                            copy_nonoverlapping(element as *const T, stage.add(value * STAGE + filled[value]), 1);
+                        }
+                        filled[value] += 1;
+                        if filled[value] == STAGE {
+                            unsafe { copy_nonoverlapping(stage.add(value * STAGE), dst.0.add(cursor[value]), STAGE) };
+                            cursor[value] += STAGE;
+                            filled[value] = 0;
+                        }
+                    }
+                    for value in 0..256 {
+                        if filled[value] > 0 {
+                            unsafe { copy_nonoverlapping(stage.add(value * STAGE), dst.0.add(cursor[value]), filled[value]) };
+                        }
+                    }
+                });
+            }
+        });
+    }
+    if T::NUMBER_OF_DIGITS % 2 == 1 {
+        // odd number of passes: the result sits in the scratch buffer (mod.rs:170-174)
+        unsafe { copy_nonoverlapping(scratch_ptr as *const T, slice_ptr, n) };
+    }
+    // `scratch` holds MaybeUninit<T>: dropping it runs no destructor, the elements live on in `data`
 }

@@ -97,3 +97,20 @@ def test_golden_fixtures(orc):
         if int(n) <= 1000:
             assert np.array_equal(orc.numpy_stable_sort(raw, lay), exp), k
         assert np.array_equal(util.make_input(t, int(n), dist, int(seed)), raw), "fixture input not reproducible: " + k
+
+
+# ---- the reference's optimisation ladder radix_sort0..5 + counting_sort (mod.rs:40-59,178-571) ----
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("t", ["u8", "u16", "u32", "i64", "f32", "(u64,u64)", "(u8,u8)", "u128", "(u32,[u8;8])"])
+def test_cpu_ladder_variants_agree(orc, t, variant):
+    lay = orc.Layout(*util.TYPES[t])
+    for n, dist, threads in ((1, "uniform", 3), (2, "uniform", 8), (1000, "two", 7), (65537, "uniform", 5), (40001, "zipf", 2)):
+        raw = util.make_input(t, n, dist, seed=n + variant)
+        assert np.array_equal(orc.sort_variant(raw, lay, threads, variant), orc.numpy_stable_sort(raw, lay)), (t, variant, n, dist)
+
+
+def test_counting_sort_bytes(orc):
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 255, 100003):
+        a = rng.integers(0, 256, size=n, dtype=np.uint8)
+        assert np.array_equal(orc.counting_sort(a), np.sort(a, kind="stable"))

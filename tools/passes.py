@@ -9,6 +9,7 @@ import bench
 L = _lib.load()
 L.rsx_debug_sweep_times.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_int]
 ctx = rs.default_context(0)
+if os.environ.get('HOT_LANES'): ctx.set_option(rs.OPT_HOT_LANES, int(os.environ['HOT_LANES']))
 for wl in sys.argv[1:] or ["c2-256m-u32"]:
     t, logn, gen, param, _ = bench.WORKLOADS[wl]
     d = bench.digits_for(rs, t)
