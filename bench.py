@@ -308,8 +308,8 @@ def main():
     allk = [torch.zeros(8, dtype=torch.int64, device=cdev) for _ in range(world)]
     dist.all_gather(allk, mine.to(cdev))
     keys = []
-    for t in allk:
-        a = [int(v) for v in t.cpu().tolist()]
+    for gathered in allk:
+        a = [int(v) for v in gathered.cpu().tolist()]
         keys.append((a[0] << 96 | a[1] << 64 | a[2] << 32 | a[3], a[4] << 96 | a[5] << 64 | a[6] << 32 | a[7]))
     for r in range(world - 1):
         assert keys[r][1] <= keys[r + 1][0], f"order broken between rank {r} and {r + 1}"

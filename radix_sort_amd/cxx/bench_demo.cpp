@@ -37,23 +37,35 @@ uint64_t mix(uint64_t x) {  // splitmix64
     return x ^ (x >> 31);
 }
 
-// KeyUniform (distr.rs): uniform key, payload 0 -- filled by all host threads (not timed)
+// KeyUniform (distr.rs): uniform key, payload 0 -- filled by all host threads (not timed).  With
+// `index_payload` (--check) the payload is the element's index instead, which makes instability visible.
 template <typename K>
-void fill_uniform(std::vector<std::pair<K, K>>& v, uint64_t seed) {
+void fill_uniform(std::vector<std::pair<K, K>>& v, uint64_t seed, bool index_payload = false) {
     const unsigned nt = std::max(1u, std::thread::hardware_concurrency());
     std::vector<std::thread> th;
     const size_t n = v.size();
     for (unsigned t = 0; t < nt; ++t)
         th.emplace_back([&, t] {
-            for (size_t i = n * t / nt; i < n * (t + 1) / nt; ++i) v[i] = {(K)mix(seed + i), K(0)};
+            for (size_t i = n * t / nt; i < n * (t + 1) / nt; ++i) v[i] = {(K)mix(seed + i), index_payload ? (K)i : K(0)};
         });
     for (auto& x : th) x.join();
 }
 
+// order-independent checksum of the elements (the sort must keep the multiset)
 template <typename K>
-bool is_sorted_by_key(const std::vector<std::pair<K, K>>& v) {
-    for (size_t i = 1; i < v.size(); ++i)
+uint64_t multiset_sum(const std::vector<std::pair<K, K>>& v) {
+    uint64_t s = 0;
+    for (const auto& e : v) s += mix((uint64_t)e.first * 0x9E3779B97F4A7C15ull ^ (uint64_t)e.second);
+    return s;
+}
+
+// ascending by key; equal keys in ascending payload (= original index under --check): the stable order
+template <typename K>
+bool is_sorted_stably(const std::vector<std::pair<K, K>>& v, bool payload_is_index) {
+    for (size_t i = 1; i < v.size(); ++i) {
         if (v[i - 1].first > v[i].first) return false;
+        if (payload_is_index && v[i - 1].first == v[i].first && v[i - 1].second > v[i].second) return false;
+    }
     return true;
 }
 
@@ -68,12 +80,13 @@ double time_host(double gb, int runs, bool check) {
     std::vector<std::pair<K, K>> data(n);
     double total = 0;
     for (int r = 0; r < runs; ++r) {
-        fill_uniform(data, 0x5EED0000ull + (uint64_t)r * 0x100000000ull);
+        fill_uniform(data, 0x5EED0000ull + (uint64_t)r * 0x100000000ull, check);
+        const uint64_t before = check ? multiset_sum(data) : 0;
         const auto t0 = Clock::now();
         rsx::radix_sort(data);  // the drop-in: <[T]>::radix_sort(&mut self)
         total += std::chrono::duration<double>(Clock::now() - t0).count();
-        if (check && !is_sorted_by_key(data)) {
-            std::fprintf(stderr, "NOT SORTED\n");
+        if (check && (!is_sorted_stably(data, true) || multiset_sum(data) != before)) {
+            std::fprintf(stderr, "NOT SORTED / NOT STABLE / ELEMENTS CHANGED\n");
             std::exit(2);
         }
     }
@@ -152,11 +165,12 @@ int bench_files(int argc, char** argv, int first) {
         std::vector<std::pair<K, K>> v((size_t)bytes / sizeof(std::pair<K, K>));  // main.rs:59: len / size_of::<T>()
         if (std::fread(v.data(), sizeof(v[0]), v.size(), f) != v.size()) return 1;
         std::fclose(f);
+        const uint64_t before = multiset_sum(v);
         const auto t0 = Clock::now();
         rsx::radix_sort(v);
         total += std::chrono::duration<double>(Clock::now() - t0).count();
         ++files;
-        if (!is_sorted_by_key(v)) {
+        if (!is_sorted_stably(v, false) || multiset_sum(v) != before) {
             std::fprintf(stderr, "NOT SORTED: %s\n", argv[i]);
             return 2;
         }

@@ -89,7 +89,10 @@ template <typename K, typename U>
 struct RadixDigits<std::pair<K, U>> {
     static constexpr uint8_t NUMBER_OF_DIGITS = RadixDigits<K>::NUMBER_OF_DIGITS;
     static rsx_layout layout() {
-        static_assert(std::is_trivially_copyable<std::pair<K, U>>::value || true, "elements are moved bitwise");
+        // elements are moved bitwise (mod.rs:133-140 uses copy_nonoverlapping); std::pair itself is never
+        // "trivially copyable" (user-provided assignment), so the requirement is put on its members
+        static_assert(std::is_trivially_copyable<K>::value && std::is_trivially_copyable<U>::value,
+                      "radix_sort moves elements bitwise: key and payload must be trivially copyable");
         const std::pair<K, U>* p = nullptr;
         const uint32_t off = (uint32_t)(reinterpret_cast<const char*>(&p->first) - reinterpret_cast<const char*>(p));
         rsx_layout k = RadixDigits<K>::layout();
@@ -115,6 +118,12 @@ public:
         if (rc != RSX_OK)
             throw std::runtime_error(std::string(what) + ": " + rsx_strerror(rc) + " (" + rsx_last_error(ctx_) + ")");
     }
+    // rsx_ctx_check: synchronises `stream` and throws if a kernel of this context gave up a device-side
+    // wait.  The stream-ordered radix_sort_device cannot report that by itself (the reference's analogue
+    // is the worker panic of mod.rs:106): call this where you synchronise.
+    void synchronize_and_check(void* stream = nullptr) const { check(rsx_ctx_check(ctx_, stream), "rsx_ctx_check"); }
+    // rsx_ctx_set_option: force one of the bit-exact alternative kernel paths (RSX_OPT_*)
+    void set_option(int option, uint64_t value) const { check(rsx_ctx_set_option(ctx_, option, value), "rsx_ctx_set_option"); }
 
 private:
     rsx_ctx* ctx_ = nullptr;
@@ -135,7 +144,8 @@ template <typename T>
 void radix_sort(std::vector<T>& v, Context& ctx = default_context()) {
     radix_sort(v.data(), v.size(), ctx);
 }
-// Device-resident form: `d_tmp` is the reference's `temp` (mod.rs:71-83); stream-ordered.
+// Device-resident form: `d_tmp` is the reference's `temp` (mod.rs:71-83); stream-ordered, not synchronised.
+// A device-side failure surfaces at ctx.synchronize_and_check(stream) (or at the next sort on the context).
 template <typename T>
 void radix_sort_device(T* d_data, T* d_tmp, size_t n, void* stream = nullptr, Context& ctx = default_context()) {
     const rsx_layout L = RadixDigits<T>::layout();
