@@ -186,6 +186,9 @@ def main():
                     help="multi-GPU schedule: 'first' = partition by the top digit, ONE all-to-all, one local sort (default); "
                          "'one' = local sort, one all-to-all, local sort; 'per-pass' = one all-to-all per digit pass "
                          "(the reference's loop with chunk == GPU, the north star's wording)")
+    ap.add_argument("--chunks", type=int, default=4,
+                    help="--exchange first: ranges the exchange is cut into so that the local sort of one range runs while "
+                         "the next ones are on the links (1 = no overlap)")
     args = ap.parse_args()
     if args.workload is None:
         args.workload = "c2-256m-u32" if args.gpus <= 1 else "c4-slice-512m-u32"
@@ -264,7 +267,7 @@ def main():
     def fill(i, b):
         ctx.generate_device(b.data_ptr(), n, d, gen_id(rs, gen), 0x5EED0000 + i, param, rank * n, stream)
 
-    run = {"first": lambda b: sorter.sort_exchange_first(b, d, n_per_rank),
+    run = {"first": lambda b: sorter.sort_exchange_first(b, d, n_per_rank, chunks=args.chunks),
            "one": lambda b: sorter.sort_one_exchange(b, d, n_per_rank),
            "per-pass": lambda b: sorter.sort(b, d, n_per_rank)}[args.exchange]
     wbuf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
@@ -325,7 +328,7 @@ def main():
                        "n_keys_per_gpu": n, "elem_bytes": d.elem_bytes, "passes": d.key_bytes, "radix_bits": 8,
                        "generator": gen,
                        "exchange": {"first": "partition by the top digit + all-gather(256 x u64) + exact cuts inside boundary buckets + "
-                                             "ONE all-to-all-v + one local sort",
+                                             "ONE all-to-all-v in %d batches, each range sorted while the next is on the links" % args.chunks,
                                     "one": "local sort + 256-way splitter search (1 all-reduce per digit) + ONE all-to-all-v + local sort",
                                     "per-pass": "per-pass all-gather(256 x u64) + all-to-all-v"}[args.exchange] +
                                    (" (RCCL)" if args.backend == "nccl" else " (gloo, host-staged: rehearsal only)"),

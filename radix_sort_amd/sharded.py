@@ -266,8 +266,14 @@ class ShardedRadixSort:
             self.dist.all_to_all_single(recv, send, output_split_sizes=(recv_counts * es).tolist(),
                                         input_split_sizes=(send_counts * es).tolist(), group=self.group)
 
-    def sort_exchange_first(self, x, d: RadixDigits, n_per_rank: Optional[List[int]] = None):
-        """Same contract as `sort`.  Partition by the top digit, exchange once, sort once."""
+    def sort_exchange_first(self, x, d: RadixDigits, n_per_rank: Optional[List[int]] = None, chunks: int = 1):
+        """Same contract as `sort`.  Partition by the top digit, exchange once, sort once.
+
+        chunks > 1 pipelines the exchange with the local sort: what a rank receives is cut into `chunks`
+        consecutive ranges of top-digit values of about equal size; the pieces of range c travel as one
+        batch of sends/receives, and range c is sorted (it is final: the ranges are ordered by key) while
+        the batches behind it are still on the links.  xGMI moves a slice more slowly than the GPU sorts
+        it, so this hides the local sort behind the exchange but for the last range."""
         be = self.backend
         es, G, me = d.elem_bytes, self.world, self.rank
         n_local = x.numel() // es
@@ -348,11 +354,81 @@ class ShardedRadixSort:
         send_counts = np.diff(split[me])
         recv_counts = split[:, me + 1] - split[:, me]
         assert send_counts.sum() == n_local and recv_counts.sum() == n_local, (send_counts, recv_counts)
+        if chunks > 1 and G > 1:
+            self._pipelined_exchange_and_sort(x, part, d, split, lstart, chunks)
+            be.finish()
+            return
         # 3. the one exchange, straight back into the slice; 4. one local sort
         self._exchange(part, x, send_counts, recv_counts, es)
         if n_local > 1:
             be.sort(x, part, n_local, d)
         be.finish()
+
+    def _pipelined_exchange_and_sort(self, x, part, d: RadixDigits, split: np.ndarray, lstart: np.ndarray, chunks: int):
+        """Steps 3 and 4 of `sort_exchange_first`, overlapped.  split[g][h]..split[g][h+1] of rank g's
+        partitioned slice goes to rank h; lstart[g][v] is where top-digit bucket v starts in it.  Every rank
+        derives the same plan from these two tables."""
+        import torch
+        dist, be = self.dist, self.backend
+        es, G, me = d.elem_bytes, self.world, self.rank
+        n_local = x.numel() // es
+        # cnt[g][h][v]: elements of rank g's bucket v that go to rank h (overlap of the bucket with h's range)
+        lo = np.maximum(lstart[:, None, :-1], split[:, :-1, None])
+        hi = np.minimum(lstart[:, None, 1:], split[:, 1:, None])
+        cnt = np.clip(hi - lo, 0, None)  # [G][G][256]
+        # ranges of top-digit values, per destination, of about equal size: boundaries by cumulative count
+        tot = cnt.sum(axis=0)  # [h][v]
+        cum = np.cumsum(tot, axis=1)
+        edges = np.zeros((G, chunks + 1), dtype=np.int64)  # bucket index where chunk c of destination h starts
+        for h in range(G):
+            n_h = cum[h, -1]
+            for c in range(1, chunks):
+                edges[h, c] = int(np.searchsorted(cum[h], (n_h * c) // chunks, side="right"))
+            edges[h, chunks] = 256
+            edges[h] = np.maximum.accumulate(edges[h])
+        # size[g][h][c]: what g sends to h in batch c (one contiguous piece: buckets are in order inside g's range for h)
+        size = np.zeros((G, G, chunks), dtype=np.int64)
+        for h in range(G):
+            for c in range(chunks):
+                size[:, h, c] = cnt[:, h, edges[h, c]:edges[h, c + 1]].sum(axis=1)
+        send_off = split[me, :-1, None] + np.cumsum(size[me], axis=1) - size[me]  # [h][c] offsets in `part`
+        csize = size[:, me, :].sum(axis=0)  # my chunk sizes
+        coff = np.concatenate(([0], np.cumsum(csize)))
+        recv_off = coff[None, :-1] + np.cumsum(size[:, me, :], axis=0) - size[:, me, :]  # [g][c] offsets in x
+        assert coff[-1] == n_local
+        scratch = self._buf("sort_scratch", int(csize.max()) * es if n_local else 0)
+
+        def piece(buf, off, ln):
+            return buf[int(off) * es:int(off + ln) * es]
+
+        staged = self.host_staged and x.is_cuda
+        works = []
+        for c in range(chunks):
+            ops, landing = [], []
+            for k in range(1, G):  # ring order: every link starts busy
+                h, g = (me + k) % G, (me - k) % G
+                if size[me, h, c]:
+                    src = piece(part, send_off[h, c], size[me, h, c])
+                    ops.append(dist.P2POp(dist.isend, src.cpu() if staged else src, h, group=self.group))
+                if size[g, me, c]:
+                    dst = piece(x, recv_off[g, c], size[g, me, c])
+                    if staged:
+                        host = torch.empty(dst.numel(), dtype=torch.uint8)
+                        landing.append((dst, host))
+                        dst = host
+                    ops.append(dist.P2POp(dist.irecv, dst, g, group=self.group))
+            reqs = dist.batch_isend_irecv(ops) if ops else []
+            if size[me, me, c]:  # my own piece: a local copy
+                piece(x, recv_off[me, c], size[me, me, c]).copy_(piece(part, send_off[me, c], size[me, me, c]))
+            works.append((reqs, landing))
+        for c in range(chunks):
+            reqs, landing = works[c]
+            for r in reqs:
+                r.wait()  # (RCCL: the compute stream waits, not the host)
+            for dst, host in landing:
+                dst.copy_(host)
+            if csize[c] > 1:
+                be.sort(piece(x, coff[c], csize[c]), scratch[:int(csize[c]) * es], int(csize[c]), d)
 
     def sort(self, x, d: RadixDigits, n_per_rank: Optional[List[int]] = None):
         """x: this rank's slice as a contiguous uint8 tensor (n_local * elem_bytes).  In place."""

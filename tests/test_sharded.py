@@ -87,8 +87,8 @@ def _worker(rank, world, port, tname, dist_name, sizes, outdir, schedule="per-pa
         mine = full[off * d.elem_bytes:(off + sizes[rank]) * d.elem_bytes].copy()
         x = torch.from_numpy(mine)
         sorter = ShardedRadixSort(backend=OracleBackend())
-        {"per-pass": sorter.sort, "one": sorter.sort_one_exchange, "first": sorter.sort_exchange_first}[schedule](
-            x, d, n_per_rank=list(sizes))
+        {"per-pass": sorter.sort, "one": sorter.sort_one_exchange, "first": sorter.sort_exchange_first,
+         "pipelined": lambda *a, **k: sorter.sort_exchange_first(*a, chunks=3, **k)}[schedule](x, d, n_per_rank=list(sizes))
         np.save(os.path.join(outdir, f"out{rank}.npy"), x.numpy())
     finally:
         dist.destroy_process_group()
@@ -122,7 +122,7 @@ def test_sharded_gloo_matches_single_sort(orc, tmp_path, world, tname, dist_name
     (3, "(u8,u8)", "uniform", (900, 1100, 1000)),  # one-digit keys: the top digit is the whole key
     (3, "u32", "sorted", (2000, 1, 3000)),
 ])
-@pytest.mark.parametrize("schedule", ["one", "first"])
+@pytest.mark.parametrize("schedule", ["one", "first", "pipelined"])
 def test_one_exchange_gloo_matches_single_sort(orc, tmp_path, world, tname, dist_name, sizes, schedule):
     import torch.multiprocessing as mp
     port = _free_port()
@@ -179,8 +179,8 @@ def _gpu_worker(rank, world, port, tname, dist_name, sizes, outdir, schedule="pe
         off = sum(sizes[:rank])
         x = torch.from_numpy(full[off * d.elem_bytes:(off + sizes[rank]) * d.elem_bytes].copy()).cuda()
         sorter = ShardedRadixSort()  # product backend: HIP through the C-ABI
-        {"per-pass": sorter.sort, "one": sorter.sort_one_exchange, "first": sorter.sort_exchange_first}[schedule](
-            x, d, n_per_rank=list(sizes))
+        {"per-pass": sorter.sort, "one": sorter.sort_one_exchange, "first": sorter.sort_exchange_first,
+         "pipelined": lambda *a, **k: sorter.sort_exchange_first(*a, chunks=4, **k)}[schedule](x, d, n_per_rank=list(sizes))
         np.save(os.path.join(outdir, f"out{rank}.npy"), x.cpu().numpy())
     finally:
         dist.destroy_process_group()
@@ -210,7 +210,7 @@ def test_sharded_hip_two_ranks_one_gpu(orc, tmp_path, tname, dist_name, sizes):
     ("(u32,u32)", "two", (200000, 123457)),
     ("i16", "equal", (65536, 70000)),
 ])
-@pytest.mark.parametrize("schedule", ["one", "first"])
+@pytest.mark.parametrize("schedule", ["one", "first", "pipelined"])
 def test_one_exchange_hip_two_ranks_one_gpu(orc, tmp_path, tname, dist_name, sizes, schedule):
     import torch.multiprocessing as mp
     port = _free_port()
