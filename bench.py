@@ -241,6 +241,7 @@ def main():
                 extra[wl]["sweep_gbps"] = r.get("sweep_gbps")
                 extra[wl]["sweep_frac_of_hbm_peak"] = (r.get("sweep_gbps") or 0.0) / HBM_PEAK_GBPS
                 extra[wl]["steps"] = args.steps
+                extra[wl]["sweep_traffic_bytes_per_launch"] = pmc_traffic(wl)
             except Exception as e:  # noqa: BLE001  (an extra must never kill the headline)
                 extra[wl] = {"error": repr(e)}
         if extra:
