@@ -338,7 +338,7 @@ int rsx_ctx_check(rsx_ctx* ctx, void* stream) try {
     if (*e) {
         if (ctx->busy) (void)hipEventSynchronize(ctx->last_event);  // nothing of this context may still be running
         *e = 0;
-        return fail(ctx, RSX_ERR_INTERNAL, "look-back spin gave up (device protocol error)");
+        return fail(ctx, RSX_ERR_INTERNAL, "look-back spin gave up, or an atomic rank failed its cross-check (device protocol error)");
     }
     return RSX_OK;
 } catch (...) {
@@ -381,6 +381,9 @@ int rsx_ctx_set_option(rsx_ctx* ctx, int option, uint64_t value) try {
             return RSX_OK;
         case RSX_OPT_VERBOSE:
             flag(OPT_VERBOSE, value != 0);
+            return RSX_OK;
+        case RSX_OPT_RANK_CHECK:
+            flag(OPT_RANK_CHECK, value != 0);
             return RSX_OK;
         default:
             return fail(ctx, RSX_ERR_ARG, "unknown option");

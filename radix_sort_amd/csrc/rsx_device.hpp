@@ -351,6 +351,7 @@ struct SweepArgs {
 constexpr uint32_t SWEEP_OPT_DYNAMIC = 1u;       // ticketed tiles, no roll call
 constexpr uint32_t SWEEP_OPT_NO_XCD_MAJOR = 2u;  // workgroups numbered by plain blockIdx
 constexpr uint32_t SWEEP_OPT_AGENT_STATUS = 4u;  // agent-scope status stores on every chain
+constexpr uint32_t SWEEP_OPT_RANK_CHECK = 8u;    // cross-check one round of atomic ranks per tile against the ballots
 #ifdef RSX_TUNING
 #define RSX_DBG(a, bit) ((a).dbg & (bit))
 #else
@@ -793,6 +794,17 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                     if constexpr (ATOM) {
                         below[r] = 0;
                         word[r] = atomicAdd(cnt, 1u << sh[r]);
+                        // RSX_OPT_RANK_CHECK (tests): the ordering the atomic ranks rest on, checked on REAL sweeps
+                        // -- under whatever LDS contention the co-resident workgroups make -- not only by the
+                        // idle-device self-test: within one instruction, the value returned to a lane must exceed
+                        // the value returned to the first lane of its digit by the number of lower lanes with
+                        // that digit.  One round per tile; a mismatch raises the context's error word.
+                        if ((a.opts & SWEEP_OPT_RANK_CHECK) && j == 1) {
+                            const uint64_t m = match_digit(d);
+                            const uint32_t mine = (word[r] >> sh[r]) & (WIDE_CNT ? ~0u : 0xFFFFu);
+                            const uint32_t first = (uint32_t)__shfl((int)mine, (int)__builtin_ctzll(m));
+                            if (mine - first != mbcnt64(m)) __hip_atomic_store(a.error, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
                     } else {
                         uint64_t m;
                         if constexpr (FULL && JB != 0) {

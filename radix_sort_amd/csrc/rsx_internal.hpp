@@ -48,6 +48,7 @@ enum : uint32_t {
     OPT_NO_XCD_MAJOR = 1u << 4,    // plain blockIdx numbering
     OPT_GENERAL_BYTES = 1u << 5,   // one-byte elements through the general pass
     OPT_VERBOSE = 1u << 6,
+    OPT_RANK_CHECK = 1u << 7,      // cross-check atomic ranks against ballots on real tiles (tests)
 };
 
 }  // namespace rsxh

@@ -312,6 +312,30 @@ def test_alternative_kernel_paths_match(rs, torch, orc, opt, value, what):
     c.close()
 
 
+def test_atomic_ranks_cross_checked_under_load(rs, torch, orc):
+    """per-pass stability rests on the LDS applying same-address lanes of one ds_add_rtn in lane
+    order.  rsx_lds_order_kernel tests that on an idle device; RSX_OPT_RANK_CHECK checks one round of every
+    tile of REAL sweeps (two workgroups per CU hammering the LDS) against the ballot-derived ranks."""
+    c = rs.Context(torch.cuda.current_device())
+    c.set_option(rs.OPT_RANK_CHECK, 1)
+    out = torch.zeros(3, dtype=torch.int64, device="cuda")
+    for t, logn, gen, param in (("u32", 28, rs.GEN_UNIFORM, 0.0), ("u32", 26, rs.GEN_ZIPF, 1.0), ("u64", 27, rs.GEN_UNIFORM, 0.0),
+                                ("(u64,u64)", 26, rs.GEN_STEP, 16.0), ("u16", 27, rs.GEN_UNIFORM, 0.0)):
+        d = _digits(rs, t)
+        n = 1 << logn
+        x = torch.empty(n * d.elem_bytes, dtype=torch.uint8, device="cuda")
+        tmp = torch.empty_like(x)
+        for rep in range(3):
+            c.generate_device(x.data_ptr(), n, d, gen, 99 + rep, param)
+            rs.radix_sort(x, digits=d, tmp=tmp, ctx=c)
+            c.check()  # raises if any cross-check failed
+        c.verify_device(x.data_ptr(), n, d, out.data_ptr())
+        v = out.cpu().tolist()
+        assert v[0] == 0 and v[2] == 0, (t, v)
+        del x, tmp
+    c.close()
+
+
 def test_options_reject_bad_values(rs, torch):
     c = rs.Context(torch.cuda.current_device())
     for opt, bad in ((rs.OPT_TILE_SCHEDULE, 2), (rs.OPT_RANKING, 3), (rs.OPT_MAX_REGIONS, 33), (rs.OPT_HOT_LANES, 1), (99, 0)):
