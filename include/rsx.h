@@ -173,6 +173,13 @@ int rsx_segmented_copy_device(rsx_ctx *ctx, const void *d_src, void *d_dst, uint
  * instead of by scan). */
 int rsx_bounds_device(rsx_ctx *ctx, const void *d_sorted, size_t n, const rsx_layout *layout,
                       const uint64_t *d_queries, uint32_t nq, uint64_t *d_out, void *stream);
+/* The same with a range per query: query i is answered inside elements [d_ranges[2i], d_ranges[2i+1]) of
+ * `d_data` (a range sorted by mapped key; different queries may name different ranges), counts relative
+ * to the range's start.  One call then serves all boundaries of the exchange-first schedule, whose
+ * sorted pieces are the top-digit buckets the boundaries fall into. */
+int rsx_bounds_ranges_device(rsx_ctx *ctx, const void *d_data, size_t n, const rsx_layout *layout,
+                             const uint64_t *d_queries, const uint64_t *d_ranges, uint32_t nq, uint64_t *d_out,
+                             void *stream);
 
 /* -- multi-GPU from one process ------------------------------------------- */
 /* Sorts the concatenation slice 0 | slice 1 | ... | slice ndev-1 as ONE array,

@@ -12,7 +12,7 @@ SYMBOLS = [
     "rsx_ctx_create", "rsx_ctx_destroy", "rsx_ctx_reserve", "rsx_ctx_check", "rsx_ctx_set_option", "rsx_ctx_get_info",
     "rsx_ctx_profile", "rsx_ctx_profile_read", "rsx_last_error",
     "rsx_strerror", "rsx_version", "rsx_sort_device", "rsx_sort_host", "rsx_histogram_device",
-    "rsx_partition_device", "rsx_segmented_copy_device", "rsx_bounds_device", "rsx_sort_sharded",
+    "rsx_partition_device", "rsx_segmented_copy_device", "rsx_bounds_device", "rsx_bounds_ranges_device", "rsx_sort_sharded",
     "rsx_sort_sharded_ex", "rsx_generate_device", "rsx_verify_device",
 ]
 
@@ -93,6 +93,7 @@ def load():
     L.rsx_partition_device.argtypes = [vp, vp, vp, sz, lp, u32, vp, vp]
     L.rsx_segmented_copy_device.argtypes = [vp, vp, vp, u32, vp, vp, vp, u32, vp]
     L.rsx_bounds_device.argtypes = [vp, vp, sz, lp, vp, u32, vp, vp]
+    L.rsx_bounds_ranges_device.argtypes = [vp, vp, sz, lp, vp, vp, u32, vp, vp]
     L.rsx_sort_sharded.argtypes = [vp, u32, vp, vp, vp, lp]
     L.rsx_sort_sharded_ex.argtypes = [vp, u32, vp, vp, vp, lp, i]
     L.rsx_generate_device.argtypes = [vp, vp, sz, lp, i, u64, ctypes.c_double, u64, vp]

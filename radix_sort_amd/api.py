@@ -185,6 +185,12 @@ class Context:
         lay = d.layout()
         self._check(self._L.rsx_bounds_device(self._h, d_sorted, n, ctypes.byref(lay), d_queries, nq, d_out, stream))
 
+    def bounds_ranges_device(self, d_data: int, n: int, d: RadixDigits, d_queries: int, d_ranges: int, nq: int, d_out: int,
+                             stream: int = 0):
+        lay = d.layout()
+        self._check(self._L.rsx_bounds_ranges_device(self._h, d_data, n, ctypes.byref(lay), d_queries, d_ranges, nq, d_out,
+                                                     stream))
+
     def generate_device(self, d_data: int, n: int, d: RadixDigits, gen: int, seed: int, param: float = 0.0,
                         index_base: int = 0, stream: int = 0):
         lay = d.layout()

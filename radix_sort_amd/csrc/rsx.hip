@@ -686,7 +686,12 @@ int rsx_segmented_copy_device(rsx_ctx* ctx, const void* d_src, void* d_dst, uint
 }
 
 int rsx_bounds_device(rsx_ctx* ctx, const void* d_sorted, size_t n, const rsx_layout* L, const uint64_t* d_queries,
-                      uint32_t nq, uint64_t* d_out, void* stream) try {
+                      uint32_t nq, uint64_t* d_out, void* stream) {
+    return rsx_bounds_ranges_device(ctx, d_sorted, n, L, d_queries, nullptr, nq, d_out, stream);
+}
+
+int rsx_bounds_ranges_device(rsx_ctx* ctx, const void* d_sorted, size_t n, const rsx_layout* L, const uint64_t* d_queries,
+                             const uint64_t* d_ranges, uint32_t nq, uint64_t* d_out, void* stream) try {
     if (!ctx) return RSX_ERR_ARG;
     if (!layout_ok(L)) return fail(ctx, RSX_ERR_ARG, "invalid rsx_layout");
     if (nq == 0) return RSX_OK;
@@ -696,7 +701,7 @@ int rsx_bounds_device(rsx_ctx* ctx, const void* d_sorted, size_t n, const rsx_la
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(rsx_bounds_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, static_cast<const uint8_t*>(d_sorted),
                        (uint64_t)n, L->elem_bytes, L->key_offset, L->key_bytes, L->key_kind, d_queries, nq, d_out,
-                       static_cast<const uint64_t*>(nullptr));
+                       d_ranges);
     RSX_HIP(hipGetLastError());
     return RSX_OK;
 } catch (...) {

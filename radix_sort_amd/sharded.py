@@ -74,6 +74,20 @@ class HipBackend:
         o = out.cpu().numpy()
         return o[:nq].copy(), o[nq:].copy()
 
+    def bounds_ranges(self, x, n: int, d: RadixDigits, q_lo: np.ndarray, q_hi: np.ndarray, beg: np.ndarray, end: np.ndarray):
+        """The same for queries that each name their own sorted range [beg, end) of x (rsx_bounds_ranges_device):
+        one launch and one round trip for all boundaries; counts are relative to the range's start."""
+        nq = len(q_lo)
+        q = np.empty((2 * nq, 2), dtype=np.uint64)
+        q[:nq, 0], q[:nq, 1] = q_lo, q_hi
+        q[nq:, 0], q[nq:, 1] = beg, end
+        dq = self.torch.from_numpy(q.view(np.int64).reshape(-1)).to(self.device)
+        out = self.torch.empty(2 * nq, dtype=self.torch.int64, device=self.device)
+        s = self.torch.cuda.current_stream().cuda_stream
+        self.ctx.bounds_ranges_device(x.data_ptr(), n, d, dq.data_ptr(), dq.data_ptr() + 16 * nq, nq, out.data_ptr(), s)
+        o = out.cpu().numpy()
+        return o[:nq].copy(), o[nq:].copy()
+
     def finish(self):
         self.ctx.check(self.torch.cuda.current_stream().cuda_stream)
 
@@ -323,27 +337,25 @@ class ShardedRadixSort:
                 else:
                     pre_hi[i] = np.uint64(v) << np.uint64(8 * (top - 8))
             j256 = np.arange(256, dtype=np.uint64)
-            lens = [int(lstart[me, v + 1] - lstart[me, v]) for _, v in inside]
+            # every boundary's queries are answered inside its own bucket's sorted piece: one call per digit
+            beg = np.array([lstart[me, v] for _, v in inside], dtype=np.uint64)
+            end = np.array([lstart[me, v + 1] for _, v in inside], dtype=np.uint64)
             for digit in range(top - 1, -1, -1):
-                less = np.zeros((nb, 256), dtype=np.int64)
-                for i, (_, v) in enumerate(inside):
-                    lo = np.repeat(pre_lo[i], 256)
-                    hi = np.repeat(pre_hi[i], 256)
-                    if digit < 8:
-                        lo = lo | (j256 << np.uint64(8 * digit))
-                    else:
-                        hi = hi | (j256 << np.uint64(8 * (digit - 8)))
-                    less[i], _ = be.bounds(piece(part, v), lens[i], d, lo, hi)
-                gl = self._all_reduce_sum(less.reshape(-1), x.device).reshape(nb, 256)
+                lo = np.repeat(pre_lo[:, None], 256, axis=1)
+                hi = np.repeat(pre_hi[:, None], 256, axis=1)
+                if digit < 8:
+                    lo |= j256[None, :] << np.uint64(8 * digit)
+                else:
+                    hi |= j256[None, :] << np.uint64(8 * (digit - 8))
+                less, _ = be.bounds_ranges(part, n_local, d, lo.reshape(-1), hi.reshape(-1), np.repeat(beg, 256), np.repeat(end, 256))
+                gl = self._all_reduce_sum(less, x.device).reshape(nb, 256)
                 j = ((gl <= rank_in[:, None]).sum(axis=1) - 1).astype(np.uint64)
                 if digit < 8:
                     pre_lo |= j << np.uint64(8 * digit)
                 else:
                     pre_hi |= j << np.uint64(8 * (digit - 8))
-            mine = np.zeros((2, nb), dtype=np.int64)
-            for i, (_, v) in enumerate(inside):
-                l, q = be.bounds(piece(part, v), lens[i], d, pre_lo[i:i + 1], pre_hi[i:i + 1])
-                mine[0, i], mine[1, i] = l[0], q[0]
+            l_me, q_me = be.bounds_ranges(part, n_local, d, pre_lo, pre_hi, beg, end)
+            mine = np.stack([l_me, q_me]).astype(np.int64)
             M = self._all_gather_i64(mine.reshape(-1), x.device).reshape(G, 2, nb)
             less, eq = M[:, 0, :], M[:, 1, :] - M[:, 0, :]
             need = rank_in - less.sum(axis=0)  # elements equal to the boundary key that go below the cut

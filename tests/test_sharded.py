@@ -65,6 +65,18 @@ class OracleBackend:
         leq = np.array([bisect.bisect_right(keys, q) for q in qs], dtype=np.int64)
         return less, leq
 
+    def bounds_ranges(self, x, n, d, q_lo, q_hi, beg, end):
+        less = np.zeros(len(q_lo), dtype=np.int64)
+        leq = np.zeros(len(q_lo), dtype=np.int64)
+        es = d.elem_bytes
+        cache = {}
+        for i, (b, e) in enumerate(zip(beg.tolist(), end.tolist())):
+            if (b, e) not in cache:
+                cache[(b, e)] = x[int(b) * es:int(e) * es]
+            l, q = self.bounds(cache[(b, e)], int(e - b), d, q_lo[i:i + 1], q_hi[i:i + 1])
+            less[i], leq[i] = l[0], q[0]
+        return less, leq
+
     def finish(self):
         pass
 
