@@ -160,6 +160,30 @@ class ShardedRadixSort:
         # gloo moves host memory only: device slices are staged through the host for the two
         # collectives (test rigs: several ranks on one GPU).  RCCL ("nccl") runs device to device.
         self.host_staged = dist.get_backend(group) == "gloo"
+        # RSX_SHARD_TIMING=1: rank 0 prints where a sort_exchange_first call spends its time (each mark
+        # synchronises the device: diagnostics only, it serialises what the schedule overlaps)
+        import os
+        self.timing = os.environ.get("RSX_SHARD_TIMING", "0") not in ("", "0") and self.rank == 0
+        self._marks = []
+
+    def _mark(self, label: str):
+        if not self.timing:
+            return
+        import time
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        except ImportError:
+            pass
+        self._marks.append((label, time.perf_counter()))
+
+    def _report(self):
+        if self.timing and len(self._marks) > 1:
+            t0 = self._marks[0][1]
+            parts = [f"{b[0]} {1e3 * (b[1] - a[1]):.3f}" for a, b in zip(self._marks, self._marks[1:])]
+            print(f"[rsx sharded] total {1e3 * (self._marks[-1][1] - t0):.3f} ms: " + " | ".join(parts), flush=True)
+        self._marks = []
 
     def _buf(self, name: str, nbytes: int):
         b = self._bufs.get(name)
@@ -298,11 +322,14 @@ class ShardedRadixSort:
         bounds = np.concatenate(([0], np.cumsum(n_per_rank)))
         part = self._buf("part", n_local * es)
         top = d.key_bytes - 1
+        self._mark("start")
         # 1. one stable partition pass by the most significant digit (count + scatter, mod.rs:90-168)
         hist = be.zeros_u64(256)
         if n_local:
             be.partition(x, part, n_local, d, top, hist)
+        self._mark("partition")
         H = self._all_gather_i64(hist.cpu().numpy() if hasattr(hist, "cpu") else np.asarray(hist), x.device)  # [G][256]
+        self._mark("gather-counts")
         # 2. the buckets in global order (digit-major, rank-minor: mod.rs:110-120 with chunk == rank)
         lstart = np.concatenate([np.zeros((G, 1), np.int64), np.cumsum(H, axis=1)], axis=1)  # [G][257]
         tot = H.sum(axis=0)
@@ -322,10 +349,25 @@ class ShardedRadixSort:
         # boundary buckets: every rank sorts its piece (tmp piece in place, the old slice as scratch)
         def piece(buf, v):
             return buf[lstart[me, v] * es: lstart[me, v + 1] * es]
-        for v in sorted({v for _, v in inside}):
-            ln = int(lstart[me, v + 1] - lstart[me, v])
+        # (ONE sort over the concatenation of the pieces rather than one small sort per bucket: a piece holds one
+        # top-digit value, so sorting them together by the whole key keeps every piece where it is and sorts
+        # it -- and a small sort is mostly launch overhead: ~0.25 ms each, G-1 of them)
+        vs = [v for v in sorted({v for _, v in inside}) if lstart[me, v + 1] - lstart[me, v] > 0]
+        if len(vs) == 1:
+            ln = int(lstart[me, vs[0] + 1] - lstart[me, vs[0]])
             if ln > 1:
-                be.sort(piece(part, v), piece(x, v), ln, d)
+                be.sort(piece(part, vs[0]), piece(x, vs[0]), ln, d)
+        elif vs:
+            import torch
+            both = torch.cat([piece(part, v) for v in vs])
+            total = both.numel() // es
+            be.sort(both, self._buf("sort_scratch", total * es), total, d)
+            off = 0
+            for v in vs:
+                ln = int(lstart[me, v + 1] - lstart[me, v]) * es
+                piece(part, v).copy_(both[off:off + ln])
+                off += ln
+        self._mark("sort-boundary-buckets")
         if inside:
             nb = len(inside)
             rank_in = np.array([bounds[b + 1] - gstart[v] for b, v in inside], dtype=np.int64)
@@ -366,15 +408,21 @@ class ShardedRadixSort:
         send_counts = np.diff(split[me])
         recv_counts = split[:, me + 1] - split[:, me]
         assert send_counts.sum() == n_local and recv_counts.sum() == n_local, (send_counts, recv_counts)
+        self._mark("exact-cuts")
         if chunks > 1 and G > 1:
             self._pipelined_exchange_and_sort(x, part, d, split, lstart, chunks)
             be.finish()
+            self._mark("exchange+sort (pipelined)")
+            self._report()
             return
         # 3. the one exchange, straight back into the slice; 4. one local sort
         self._exchange(part, x, send_counts, recv_counts, es)
+        self._mark("exchange")
         if n_local > 1:
             be.sort(x, part, n_local, d)
         be.finish()
+        self._mark("sort")
+        self._report()
 
     def _pipelined_exchange_and_sort(self, x, part, d: RadixDigits, split: np.ndarray, lstart: np.ndarray, chunks: int):
         """Steps 3 and 4 of `sort_exchange_first`, overlapped.  split[g][h]..split[g][h+1] of rank g's
