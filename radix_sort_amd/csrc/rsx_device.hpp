@@ -839,13 +839,18 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
             }
             return crowded;
         };
-        // One dominant digit per round (a constant byte, sorted input, the head of a Zipf law): the
-        // lanes holding it are ranked from a single ballot (counter read + one add by the first of
-        // them); the other lanes use the atomics under their exec mask.  The round's dominant digit
-        // is the tile's (largest group of round 0) when some lane holds it, else the first lane's.
+        // One dominant digit in the tile (a constant byte, sorted input, the head of a Zipf law): the lanes
+        // holding it are ranked from a single ballot against a running count kept in a SCALAR (no LDS
+        // traffic at all for them: same-address atomics are what skew makes expensive); the other lanes
+        // use the atomics under their exec mask.  The scalar starts from what round 0 left in the wave's
+        // counter and is added back to it once at the end.
         auto rank_hot = [&](auto is_full, uint32_t hotd) __attribute__((always_inline)) {
             constexpr bool FULL = decltype(is_full)::value;
             constexpr int RG = (KPT - 1) < RSX_RANK_GROUP ? (KPT - 1) : RSX_RANK_GROUP;
+            const uint32_t hot_sh = WIDE_CNT ? 0u : (hotd & 1u) * 16u;
+            uint32_t* hot_cnt = &my_hist2[WIDE_CNT ? hotd : (hotd >> 1)];
+            const uint32_t hot_init = (uint32_t)__builtin_amdgcn_readfirstlane((int)((*hot_cnt >> hot_sh) & (WIDE_CNT ? ~0u : 0xFFFFu)));
+            uint32_t hot_run = hot_init;  // wave-uniform
 #pragma unroll
             for (int j0 = 1; j0 < KPT; j0 += RG) {
                 uint32_t word[RG], sh[RG], below[RG];
@@ -857,22 +862,16 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                     if constexpr (!FULL) {
                         if (seg + j * WAVE >= valid) d = 255u;
                     }
-                    uint32_t hd = hotd;
-                    uint64_t h = __ballot(d == hd);
-                    if (h == 0) {  // wave-uniform
-                        hd = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
-                        h = __ballot(d == hd);
-                    }
+                    const uint64_t h = __ballot(d == hotd);
                     sh[r] = WIDE_CNT ? 0u : (d & 1u) * 16u;
-                    uint32_t* cnt = &my_hist2[WIDE_CNT ? d : (d >> 1)];
-                    if (d == hd) {
+                    if (d == hotd) {
                         below[r] = mbcnt64(h);
-                        word[r] = *cnt;
-                        if (below[r] == 0) atomicAdd(cnt, (uint32_t)__popcll(h) << sh[r]);
+                        word[r] = hot_run << sh[r];
                     } else {
                         below[r] = 0;
-                        word[r] = atomicAdd(cnt, 1u << sh[r]);
+                        word[r] = atomicAdd(&my_hist2[WIDE_CNT ? d : (d >> 1)], 1u << sh[r]);
                     }
+                    hot_run += (uint32_t)__popcll(h);
                 }
 #pragma unroll
                 for (int r = 0; r < RG; ++r) {
@@ -882,6 +881,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                     pk[j / 2] = (j & 1) ? (pk[j / 2] | (rank << 16)) : rank;
                 }
             }
+            if (lane == 0 && hot_run != hot_init) atomicAdd(hot_cnt, (hot_run - hot_init) << hot_sh);
         };
         auto match_rank = [&](auto is_full) __attribute__((always_inline)) {
             const bool crowded = rank_keys(is_full, std::false_type{}, std::integral_constant<int, 0>{});

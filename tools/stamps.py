@@ -11,7 +11,7 @@ x = torch.empty(n * d.elem_bytes, dtype=torch.uint8, device="cuda"); tmp = torch
 out = (ctypes.c_ulonglong * 128)()
 names = ["ticket+barrier", "load+match", "rank+barrier", "count/scan/offsets", "lds-scatter+barrier", "lookback+barrier", "writeout+barrier"]
 for it in range(2):
-    ctx.generate_device(x.data_ptr(), n, d, rs.GEN_UNIFORM, it)
+    ctx.generate_device(x.data_ptr(), n, d, getattr(rs, os.environ.get('GEN', 'GEN_UNIFORM')), it, float(os.environ.get('GENP', '0')))
     torch.cuda.synchronize()
     L.rsx_debug_counters(ctx._h, out, 1)
     rs.radix_sort(x, digits=d, tmp=tmp)
