@@ -1046,8 +1046,17 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                 return (r << 8) | elem_digit<ES, false>(x, a.next);
             };
             if (full) {
-                auto write_full = [&](auto crowd) __attribute__((always_inline)) {  // duplicated: plain LDS atomics / skew-proof counting
+                auto write_full = [&](auto crowd, uint32_t hot_nd) __attribute__((always_inline)) {  // duplicated: plain LDS atomics / skew-proof counting
                     constexpr bool CROWD = decltype(crowd)::value;
+                    // CROWD: the hot next digit's elements are counted in a SCALAR per wave (one ballot and one
+                    // population count per instruction, no LDS traffic), keyed by the bin hot_bin = (region, hot
+                    // digit); the scalar is flushed when the wave's slots move on to another region, and at the
+                    // end of the tile.  Lanes on other bins add 1 each under their exec mask.
+                    uint32_t hot_bin = ~0u, hot_acc = 0;
+                    auto hot_flush = [&]() __attribute__((always_inline)) {
+                        if (hot_acc != 0 && lane == 0) atomicAdd(&s_jn[hot_bin], hot_acc);
+                        hot_acc = 0;
+                    };
 #pragma unroll
                     for (int i = 0; i < KPT; ++i) {
                         const uint32_t p = i * WG + tid;
@@ -1061,24 +1070,43 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                             dst[idx] = x;
                         }
                         if constexpr (NEXT) {
-                            if constexpr (CROWD) count_next(s_jn, next_bin(idx, x));
-                            else if (!RSX_DBG(a, 0x8u)) atomicAdd(&s_jn[next_bin(idx, x)], 1u);  // (0x8: ablation, no next-pass count)
+                            if constexpr (CROWD) {
+                                const uint32_t bin = next_bin(idx, x);
+                                uint64_t same = __ballot(bin == hot_bin);
+                                if (same == 0) {  // wave-uniform: no lane on the remembered bin -- the wave's slots have moved on
+                                    hot_flush();
+                                    // to another destination region: the tile's hot digit there (the head of a Zipf law) ...
+                                    hot_bin = ((uint32_t)__builtin_amdgcn_readfirstlane((int)(bin >> 8)) << 8) | hot_nd;
+                                    same = __ballot(bin == hot_bin);
+                                    if (same == 0) {  // ... or to another run of equal keys (few distinct values): the first lane's bin
+                                        hot_bin = (uint32_t)__builtin_amdgcn_readfirstlane((int)bin);
+                                        same = __ballot(bin == hot_bin);
+                                    }
+                                }
+                                hot_acc += (uint32_t)__popcll(same);
+                                if (bin != hot_bin) atomicAdd(&s_jn[bin], 1u);
+                            } else if (!RSX_DBG(a, 0x8u)) {
+                                atomicAdd(&s_jn[next_bin(idx, x)], 1u);  // (0x8: ablation, no next-pass count)
+                            }
                         }
                         // (element by element on purpose: issuing a group's LDS reads ahead of its atomics was
                         // measured no faster on u32 and slower on 8/16-byte elements)
                         if (i % RSX_WO_GROUP == RSX_WO_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
                     }
+                    if constexpr (NEXT && CROWD) hot_flush();
                 };
                 // Same-address LDS atomics serialise.  One probe per wave and tile: if a quarter of the
                 // wave's first 64 elements share their next digit, count the careful way (per-element
                 // check, wave match on crowded bins); else one plain atomic per element.
                 bool crowded_next = false;
+                uint32_t hot_nd = 0;
                 if (NEXT) {
                     const uint32_t nd = elem_digit<ES, false>(s_elems[sw0], a.next);
-                    crowded_next = __popcll(__ballot(nd == (uint32_t)__builtin_amdgcn_readfirstlane((int)nd))) >= 16;
+                    hot_nd = (uint32_t)__builtin_amdgcn_readfirstlane((int)nd);
+                    crowded_next = __popcll(__ballot(nd == hot_nd)) >= 16;
                 }
-                if (crowded_next) write_full(std::true_type{});
-                else write_full(std::false_type{});
+                if (crowded_next) write_full(std::true_type{}, hot_nd);
+                else write_full(std::false_type{}, 0u);
             } else {
 #pragma unroll
                 for (int i = 0; i < KPT; ++i) {
