@@ -129,8 +129,8 @@ int ensure_workspace(rsx_ctx* ctx, size_t n, const rsx_layout* L, hipStream_t st
     }
 
 int hist_dispatch(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_layout* L, uint32_t digit,
-                  unsigned long long* J, hipStream_t st) {
-    RSX_DISPATCH_ES(L->elem_bytes, launch_hist, ctx, src, g, L, digit, J, st)
+                  unsigned long long* J, unsigned long long* jclear, bool clear_status, hipStream_t st) {
+    RSX_DISPATCH_ES(L->elem_bytes, launch_hist, ctx, src, g, L, digit, J, jclear, clear_status, st)
 }
 int sweep_dispatch(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L,
                    uint32_t digit, const unsigned long long* J, unsigned long long* jnext, unsigned long long* jzero,
@@ -141,15 +141,16 @@ int sweep_dispatch(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
 // the 256 digit totals of a count matrix -> d_counts
 int launch_totals(rsx_ctx* ctx, const RegionGeom& g, const unsigned long long* J, uint64_t* d_counts, hipStream_t st) {
     LaunchTimer lt(ctx, RSX_PROF_SCAN, st);
-    hipLaunchKernelGGL(rsx_totals_kernel, dim3(1), dim3(RADIX), 0, st, J, g.num_regions, d_counts);
+    hipLaunchKernelGGL(rsx_totals_kernel, dim3(1), dim3(RADIX), 0, st, J, g.num_regions, d_counts, status32(g) ? 1u : 0u);
     RSX_HIP(hipGetLastError());
     return RSX_OK;
 }
 
-// zeroes what a sort (or a lone pass) accumulates into: count matrices 0 and 1, every pass's
-// tickets and roll-call words -- one contiguous memset
-int zero_counters(rsx_ctx* ctx, hipStream_t st) {
-    RSX_HIP(hipMemsetAsync(ctx->aux + OFF_J0, 0, OFF_ZERO_END - OFF_J0, st));
+// zeroes what a sort (or a lone pass) accumulates into before its count kernel: every pass's tickets and
+// roll-call words and the used part of count matrix 0 -- one contiguous memset (the count kernel clears
+// matrix 1, the first sweep matrix 2)
+int zero_counters(rsx_ctx* ctx, const RegionGeom& g, hipStream_t st) {
+    RSX_HIP(hipMemsetAsync(ctx->aux + OFF_TICKETS, 0, OFF_J0 - OFF_TICKETS + (size_t)J_REPL * g.num_regions * RADIX * sizeof(uint64_t), st));
     return RSX_OK;
 }
 
@@ -189,11 +190,12 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
     const uint32_t D = L->key_bytes;  // T::NUMBER_OF_DIGITS
     const RegionGeom geom = make_geom(ctx, n, L->elem_bytes);
     // count phase of pass 0 (mod.rs:90-109); later passes are counted by the sweep before them
-    rc = zero_counters(ctx, st);
+    rc = zero_counters(ctx, geom, st);
     if (rc) return rc;
-    rc = hist_dispatch(ctx, d_data, geom, L, 0, J_of(ctx, 0), st);
+    const bool counting_path = L->elem_bytes == 1 && !(ctx->options & OPT_GENERAL_BYTES);  // no sweep follows
+    rc = hist_dispatch(ctx, d_data, geom, L, 0, J_of(ctx, 0), D > 1 ? J_of(ctx, 1) : nullptr, !counting_path, st);
     if (rc) return rc;
-    if (L->elem_bytes == 1 && !(ctx->options & OPT_GENERAL_BYTES)) {
+    if (counting_path) {
         // u8 / i8: the element is its digit, so the 256 counts ARE the sorted array (same bytes as
         // the pass + copy-back of mod.rs:121-174 would leave): write the runs, skip scatter and copy
         uint64_t* totals = reinterpret_cast<uint64_t*>(J_of(ctx, 1));
@@ -618,9 +620,9 @@ int rsx_histogram_device(rsx_ctx* ctx, const void* d_src, size_t n, const rsx_la
     if (rc) return rc;
     Enqueue enq(ctx, st);
     const RegionGeom geom = make_geom(ctx, n, L->elem_bytes);
-    rc = zero_counters(ctx, st);
+    rc = zero_counters(ctx, geom, st);
     if (rc) return rc;
-    rc = hist_dispatch(ctx, d_src, geom, L, digit, J_of(ctx, 0), st);
+    rc = hist_dispatch(ctx, d_src, geom, L, digit, J_of(ctx, 0), nullptr, false, st);
     if (rc) return rc;
     return launch_totals(ctx, geom, J_of(ctx, 0), d_hist, st);  // column sums -> d_hist
 } catch (...) {
@@ -636,9 +638,9 @@ int partition_locked(rsx_ctx* ctx, const void* d_src, void* d_dst, size_t n, con
     if (rc) return rc;
     Enqueue enq(ctx, st);
     const RegionGeom geom = make_geom(ctx, n, L->elem_bytes);
-    rc = zero_counters(ctx, st);
+    rc = zero_counters(ctx, geom, st);
     if (rc) return rc;
-    rc = hist_dispatch(ctx, d_src, geom, L, digit, J_of(ctx, 0), st);
+    rc = hist_dispatch(ctx, d_src, geom, L, digit, J_of(ctx, 0), nullptr, true, st);
     if (rc) return rc;
     if (d_hist) {
         rc = launch_totals(ctx, geom, J_of(ctx, 0), d_hist, st);

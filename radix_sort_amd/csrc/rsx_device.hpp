@@ -232,6 +232,19 @@ __device__ __forceinline__ uint64_t match_digit_sched(uint32_t d) {
 // (the 8 XCD L2s are not coherent), ~0.5 us under load, and a single chain has ~40
 // tiles in the aggregate-only state at any time -- more status traffic than key traffic.
 constexpr int MAX_REGIONS = 32;
+// A count matrix is kept in J_REPL replicas, [J_REPL][num_regions][256]: a workgroup adds its counts to replica
+// blockIdx % J_REPL (its XCD, as blocks are dealt), readers sum the replicas.  Device-scope atomics on one
+// 64-byte line serialise at the memory side (~12 ns each): with one matrix, 512 workgroups flushing 2048
+// counters each queued 512 deep on every line at the end of a pass (measured: 13 us per workgroup).
+constexpr int J_REPL = 8;
+// Per-pass control words: [0, MAX_REGIONS) per-region tile tickets (dynamic mode), then the roll call:
+// ROLL_DONE counts complete shards, ROLL_MODE is the verdict, and ROLL_SHARD_COUNT arrival counters each
+// on a line of its own (workgroup b arrives at shard b % 8: 64 arrivals per line instead of 512 on one).
+constexpr int ROLL_DONE = MAX_REGIONS;
+constexpr int ROLL_MODE = MAX_REGIONS + 1;
+constexpr int ROLL_SHARDS = 64;            // first shard word (the words above fill one 256-byte block)
+constexpr int ROLL_SHARD_COUNT = 8;
+constexpr int ROLL_SHARD_STRIDE = 32;      // words: 128 bytes per shard
 
 struct RegionGeom {
     uint64_t n;
@@ -250,10 +263,19 @@ struct RegionGeom {
 template <int ES, bool FLT>
 __global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restrict__ src, RegionGeom g,
                                                        DigitSpec spec, uint32_t blocks_per_region,
-                                                       unsigned long long* __restrict__ J) {
+                                                       unsigned long long* __restrict__ J,
+                                                       unsigned long long* __restrict__ jclear, uint32_t j32,
+                                                       uint4* __restrict__ zero16, uint64_t zero16_n) {
     __shared__ uint32_t lh[RADIX];
     const uint32_t tid = threadIdx.x;
     if (tid < RADIX) lh[tid] = 0;
+    // the count matrix the first sweep accumulates into (the second pass's) is cleared here
+    if (jclear != nullptr)
+        for (uint32_t i = blockIdx.x * blockDim.x + tid; i < (uint32_t)J_REPL * g.num_regions * RADIX; i += gridDim.x * blockDim.x)
+            jclear[i] = 0;
+    // ... and so are the tile status words of the first sweep (a memset launch less per sort)
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + tid; i < zero16_n; i += (uint64_t)gridDim.x * blockDim.x)
+        zero16[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const uint32_t r = blockIdx.x / blocks_per_region;
     const uint32_t sub = blockIdx.x % blocks_per_region;
@@ -299,7 +321,11 @@ __global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restric
     __syncthreads();
     if (tid < RADIX) {
         const uint32_t c = lh[tid];
-        if (c) atomicAdd(&J[r * RADIX + tid], (unsigned long long)c);
+        const uint32_t bin = ((blockIdx.x % J_REPL) * g.num_regions + r) * RADIX + tid;
+        if (c) {  // counters are 32 bit where a region holds < 2^32 elements (half the atomic bytes): status32()
+            if (j32) atomicAdd(reinterpret_cast<uint32_t*>(J) + bin, c);
+            else atomicAdd(&J[bin], (unsigned long long)c);
+        }
     }
 }
 
@@ -325,21 +351,21 @@ struct SweepArgs {
     const void* src;
     void* dst;
     RegionGeom g;
-    const unsigned long long* J;  // [num_regions][256] this pass's count matrix (count phase, mod.rs:90-109): every
+    const unsigned long long* J;  // [J_REPL][num_regions][256] (entries of type S) this pass's count matrix (count phase, mod.rs:90-109): every
                                   // workgroup derives its region's write cursors from it (prefix phase, mod.rs:110-120)
     void* status;                 // [num_regions << (region_shift - log2 TILE)][256], zeroed
-    uint32_t* tickets;            // this pass's words, zeroed: [MAX_REGIONS] per-region tile counters; [MAX_REGIONS],
-                                  // [MAX_REGIONS+1]: arrival count and mode word of the start-up roll call
-    const uint32_t* prev_mode;    // the previous pass's mode word (null on a first pass): a roll call that failed
-                                  // there is not waited for again here
+    uint32_t* tickets;            // this pass's control words, zeroed: per-region tile tickets and the roll call
+                                  // (ROLL_DONE, ROLL_MODE, ROLL_SHARDS above)
+    const uint32_t* prev_mode;    // the previous pass's verdict word of shard 0 (null on a first pass): a roll call that
+                                  // failed there is not waited for again here (each workgroup reads its own shard's copy)
     uint16_t wg_first[MAX_REGIONS + 1];  // static mode: region r is served by workgroups [wg_first[r], wg_first[r+1])
     void* status_clean;           // the next pass's status words: every tile zeroes its row there (null on a last pass)
     uint32_t rank_atomic;         // 1: ranks may come from returned LDS atomics (ordering self-test passed)
     uint32_t hot_lanes;           // a digit shared by this many lanes of round 0 sends the tile down the ballot path
     uint32_t tiles_per_region;    // ceil(region length / tile): status rows per region
     uint32_t local_mask;          // static mode: regions whose workgroups all sit in one residue class of blockIdx % 8
-    unsigned long long* jnext;    // [MAX_REGIONS][256] next pass's count matrix (accumulated), or null
-    unsigned long long* jzero;    // [MAX_REGIONS][256] count matrix of the pass after next: cleared here, or null
+    unsigned long long* jnext;    // [J_REPL][num_regions][256] next pass's count matrix (accumulated), or null
+    unsigned long long* jzero;    // same shape: count matrix of the pass after next, cleared here, or null
     uint32_t* error;              // host-visible (pinned) word: set non-zero if a bounded spin gave up
     DigitSpec spec;               // this pass's digit
     DigitSpec next;               // next pass's digit (when jnext != null)
@@ -380,6 +406,9 @@ constexpr uint32_t SWEEP_OPT_RANK_CHECK = 8u;    // cross-check one round of ato
 #endif
 #ifndef RSX_MINW
 #define RSX_MINW 6
+#endif
+#ifndef RSX_START_STAGGER
+#define RSX_START_STAGGER 224
 #endif
 #ifndef RSX_NUM_SGPR
 #define RSX_NUM_SGPR 102
@@ -542,8 +571,10 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         for (uint32_t i = threadIdx.x; i < a.g.num_regions * RADIX; i += WG) s_jn[i] = 0;
     // the count matrix of the pass after next is cleared here: its last readers (the previous pass)
     // are done, its next writers (the next pass) have not started
+    using JT = S;  // count-matrix entries: 32 bit with 32-bit status words (a region then holds <= 2^30 elements)
     if (a.jzero != nullptr)
-        for (uint32_t i = blockIdx.x * WG + threadIdx.x; i < (uint32_t)(MAX_REGIONS * RADIX); i += gridDim.x * WG) a.jzero[i] = 0;
+        for (uint32_t i = blockIdx.x * WG + threadIdx.x; i < (uint32_t)J_REPL * NR * RADIX; i += gridDim.x * WG)
+            reinterpret_cast<JT*>(a.jzero)[i] = 0;
 
     // workgroup index, XCD-major (blocks are dealt round-robin over the 8 XCDs): the workgroups of
     // one chain then share an XCD, which makes their status hand-offs faster -- never a
@@ -581,60 +612,54 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
     //    so 40000 ticks (~18 us, ~4 % of a 256M-key pass) is ample; a grid that is not co-resident
     //    (two streams, a co-tenant) costs that once per sort: the verdict carries over to the
     //    later passes through prev_mode.
-    if (threadIdx.x == 0) {
-        uint32_t mode = 2;
-        if (!(a.opts & SWEEP_OPT_DYNAMIC) &&
-            !(a.prev_mode != nullptr && __hip_atomic_load(a.prev_mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2u)) {
-            uint32_t* arrive = a.tickets + MAX_REGIONS;
-            uint32_t* modew = a.tickets + MAX_REGIONS + 1;
-            // The same word also collects whether workgroups sit where the XCD-major numbering
-            // assumes (XCC id == blockIdx % 8): low half = arrivals, high half = workgroups that do not.
-            uint32_t xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            const bool placed = (gridDim.x % 8u == 0u) && ((xcc & 0xFu) == blockIdx.x % 8u);
-            __hip_atomic_fetch_add(arrive, placed ? 1u : 0x10001u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-            uint32_t seen = 0;
-            do {
-                seen = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((seen & 0xFFFFu) == gridDim.x) break;
-                __builtin_amdgcn_s_sleep(4);
-            } while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)RSX_ROLLCALL_TICKS);
-            uint32_t expected = 0;
-            const uint32_t verdict = (seen & 0xFFFFu) != gridDim.x ? 2u : (seen == gridDim.x ? 3u : 1u);
-            __hip_atomic_compare_exchange_strong(modew, &expected, verdict, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
-            mode = __hip_atomic_load(modew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (!(a.opts & SWEEP_OPT_DYNAMIC)) {
-            // carried-over failure: record it for the pass after this one as well
-            __hip_atomic_store(a.tickets + MAX_REGIONS + 1, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        s_misc[3] = mode;
-    }
-    __syncthreads();
-    const uint32_t mode = __builtin_amdgcn_readfirstlane(s_misc[3]);  // 1/3 static, 2 dynamic, 3 = placement verified
-    const bool static_mode = mode != 2u;
-    if (RSX_DBG(a, 0x100u) && threadIdx.x == 0 && blockIdx.x == 0) {
-        atomicAdd(&a.dbg_cnt[5], static_mode ? 1ull : 0ull);
-        atomicAdd(&a.dbg_cnt[6], mode == 3u ? 1ull : 0ull);
-    }
-    // ---- prefix phase (mod.rs:110-120) -------------------------------------------------
+    // ---- prefix phase (mod.rs:110-120), first half: the counts ----------------------------------
     // Write cursor of (region r, digit v) at the region's start: the digit-major, region-minor
     // exclusive running sum of the count matrix,
     //     sum_{v' < v} sum_r' J[r'][v']  +  sum_{r' < r} J[r'][v].
-    // Every workgroup derives the 256 cursors of the region it serves itself (<= 16 x 256 counts,
-    // L2-resident); thread v keeps digit v's cursor in registers for all its tiles.
+    // Every workgroup derives the 256 cursors of the region it serves itself (J_REPL x <= 32 x 256
+    // counts); thread v keeps digit v's cursor in registers for all its tiles.  The loads are spread
+    // over all 512 threads (thread t: digit t & 255, replicas of half t >> 8), up to 32 in flight each, and
+    // for the home region they are issued AHEAD of the roll call, so they land while thread 0 polls.
     uint64_t rbase = 0;
     uint64_t* s_scan = reinterpret_cast<uint64_t*>(s_misc + 16);  // [4]
-    auto region_cursors = [&](uint32_t r) {  // every thread calls (barriers inside); r is wave-uniform
-        const uint32_t t = threadIdx.x;
-        uint64_t tot = 0, below = 0;
-        if (t < RADIX) {
-            for (uint32_t q = 0; q < NR; ++q) {
-                const uint64_t c = a.J[q * RADIX + t];
-                tot += c;
-                below += q < r ? c : 0ull;
+    uint64_t* s_half = reinterpret_cast<uint64_t*>(s_elems);       // [2][256]: the tile area is free between tiles
+    static_assert(TILE_BYTES >= 2 * RADIX * sizeof(uint64_t), "scratch of the prefix phase lives in the tile area");
+    auto load_counts = [&](uint32_t r, uint64_t& tot, uint64_t& below) {  // partial column sums of thread t
+        tot = 0;
+        below = 0;
+        constexpr uint32_t HALVES = WG >= 2 * RADIX ? 2 : 1;
+        constexpr uint32_t RPH = J_REPL / HALVES;  // replicas per thread
+        uint32_t t = threadIdx.x;
+        asm volatile("" : "+v"(t));  // opaque: the column address is not worth a register pair across the tile loop
+        if (t < HALVES * RADIX) {
+            const JT* col = reinterpret_cast<const JT*>(a.J) + (size_t)(t >> 8) * RPH * NR * RADIX + (t & 255u);
+            constexpr uint32_t QU = ES >= 16 ? 4 : 8;  // loads in flight: RPH * QU (the 16-byte kernels run at 80 VGPRs)
+            for (uint32_t q0 = 0; q0 < NR; q0 += QU) {
+#pragma unroll
+                for (uint32_t qq = 0; qq < QU; ++qq) {
+                    const uint32_t q = q0 + qq;
+                    if (q < NR) {
+#pragma unroll
+                        for (uint32_t rep = 0; rep < RPH; ++rep) {
+                            const uint64_t c = col[(size_t)(rep * NR + q) * RADIX];
+                            tot += c;
+                            below += q < r ? c : 0ull;
+                        }
+                    }
+                }
             }
+        }
+    };
+    auto scan_cursors = [&](uint64_t tot, uint64_t below) {  // every thread calls (barriers inside)
+        const uint32_t t = threadIdx.x;
+        if (WG >= 2 * RADIX && t >= RADIX && t < 2 * RADIX) {
+            s_half[t - RADIX] = tot;
+            s_half[t] = below;
+        }
+        __syncthreads();
+        if (WG >= 2 * RADIX && t < RADIX) {
+            tot += s_half[t];
+            below += s_half[RADIX + t];
         }
         uint64_t x = tot;
 #pragma unroll
@@ -651,8 +676,93 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         }
         __syncthreads();
     };
+    auto region_cursors = [&](uint32_t r) {  // r is wave-uniform
+        uint64_t tot, below;
+        load_counts(r, tot, below);
+        scan_cursors(tot, below);
+    };
+    uint64_t tot_home, below_home;
+    load_counts(home, tot_home, below_home);
+#ifdef RSX_STAMPS
+    const unsigned long long stamp_entry = __builtin_amdgcn_s_memtime();
+#endif
+    if (threadIdx.x == 0) {
+        uint32_t mode = 2;
+        const uint32_t shard = blockIdx.x % (uint32_t)ROLL_SHARD_COUNT;
+        uint32_t* my_shard = a.tickets + ROLL_SHARDS + shard * ROLL_SHARD_STRIDE;  // [0] arrivals, [1] the verdict, once known
+        if (!(a.opts & SWEEP_OPT_DYNAMIC) &&
+            !(a.prev_mode != nullptr &&
+              __hip_atomic_load(a.prev_mode + shard * ROLL_SHARD_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2u)) {
+            uint32_t* done = a.tickets + ROLL_DONE;
+            uint32_t* modew = a.tickets + ROLL_MODE;
+            // Arrivals are counted per shard (blockIdx % 8, each on its own line); the workgroup that completes a
+            // shard reports it to `done`; the one that completes `done` decides and writes the verdict into every
+            // shard's line, where that shard's workgroups poll for it.  The same words also collect whether workgroups
+            // sit where the XCD-major numbering assumes (XCC id == blockIdx % 8): low half = arrivals (shards
+            // done), high half = workgroups (shards) that do not.
+            uint32_t xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            const bool placed = (gridDim.x % 8u == 0u) && ((xcc & 0xFu) == blockIdx.x % 8u);
+            const uint32_t shard_size = (gridDim.x + (uint32_t)ROLL_SHARD_COUNT - 1u - shard) / (uint32_t)ROLL_SHARD_COUNT;
+            const uint32_t shards = gridDim.x < (uint32_t)ROLL_SHARD_COUNT ? gridDim.x : (uint32_t)ROLL_SHARD_COUNT;
+            const uint32_t mine = placed ? 1u : 0x10001u;
+            const uint32_t before = __hip_atomic_fetch_add(my_shard, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            uint32_t verdict = 2u;  // what this workgroup proposes: 2 = timed out
+            bool decide = false;
+            if (((before + mine) & 0xFFFFu) == shard_size) {  // my shard is complete: report it
+                const uint32_t rep = ((before + mine) >> 16) ? 0x10001u : 1u;
+                const uint32_t seen = __hip_atomic_fetch_add(done, rep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + rep;
+                if ((seen & 0xFFFFu) == shards) {  // ... and it was the last one: everybody is running
+                    verdict = seen == shards ? 3u : 1u;
+                    decide = true;
+                }
+            }
+            if (!decide) {  // wait for the verdict to appear in my shard's line (64 pollers per line, not 512 on one)
+                do {
+                    mode = __hip_atomic_load(my_shard + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (mode != 0u) break;
+                    __builtin_amdgcn_s_sleep(4);
+                } while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)RSX_ROLLCALL_TICKS);
+                decide = mode == 0u;  // timed out: propose dynamic mode
+            }
+            if (decide) {  // the mode word is the one source of truth: first proposal wins, then it is broadcast to the shards
+                uint32_t expected = 0;  // (a failed exchange leaves the winner's verdict here)
+                const bool won = __hip_atomic_compare_exchange_strong(modew, &expected, verdict, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                      __HIP_MEMORY_SCOPE_AGENT);
+                mode = won ? verdict : expected;
+                for (uint32_t k = 0; k < shards; ++k)
+                    __hip_atomic_store(a.tickets + ROLL_SHARDS + k * ROLL_SHARD_STRIDE + 1, mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (!(a.opts & SWEEP_OPT_DYNAMIC)) {
+            // carried-over failure: record it for the pass after this one as well
+            __hip_atomic_store(my_shard + 1, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_misc[3] = mode;
+    }
+    __syncthreads();
+    const uint32_t mode = __builtin_amdgcn_readfirstlane(s_misc[3]);  // 1/3 static, 2 dynamic, 3 = placement verified
+    const bool static_mode = mode != 2u;
+    if (RSX_DBG(a, 0x100u) && threadIdx.x == 0 && blockIdx.x == 0) {
+        atomicAdd(&a.dbg_cnt[5], static_mode ? 1ull : 0ull);
+        atomicAdd(&a.dbg_cnt[6], mode == 3u ? 1ull : 0ull);
+    }
+#ifdef RSX_STAMPS
+    const unsigned long long stamp_called = __builtin_amdgcn_s_memtime();
+#endif
     uint32_t cur_reg = home;
-    region_cursors(home);
+    scan_cursors(tot_home, below_home);
+    // Start-up stagger.  The workgroups of a chain settle into an even spread of phases over one tile period
+    // (tile t+1 trails tile t by a status hand-off), which is what lets the loads of some overlap the ranking
+    // and the stores of others.  Leaving the roll call they are all in the SAME phase -- every CU loading, then
+    // every CU storing -- until the look-back has pulled them apart.  Workgroup j of a chain therefore starts
+    // j * RSX_START_STAGGER cycles late (about half the steady-state spacing): 256M u32 2.066 -> 2.041 ms,
+    // 16M u32 222 -> 209 us; 100..300 cycles measured alike, 400 worse.
+    if (static_mode && RSX_START_STAGGER > 0) {
+        const unsigned long long ts = __builtin_amdgcn_s_memtime();
+        const unsigned long long wait = (unsigned long long)st_k * RSX_START_STAGGER;
+        while (__builtin_amdgcn_s_memtime() - ts < wait) __builtin_amdgcn_s_sleep(4);
+    }
     // A chain whose workgroups were all verified on ONE XCD shares one L2: its status words can then
     // be plain stores that stay in that L2 (an agent-scope store writes through to memory and the
     // next agent-scope load of the line misses: 750 vs 510 cycles per hand-off, tools/microbench/pingpong.hip).
@@ -694,6 +804,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
 #ifdef RSX_STAMPS
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+    const unsigned long long stamp_loop = stamp_prev;
 #endif
     while (true) {
         // thread coordinates are re-derived per tile from an opaque copy of threadIdx: otherwise
@@ -1130,17 +1241,28 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         __syncthreads();  // s_elems / s_base are reused by the next tile
         RSX_STAMP(6);
     }
-#ifdef RSX_STAMPS
-    if ((threadIdx.x & 63) == 0)
-        for (int k = 0; k < 8; ++k) atomicAdd(&a.dbg_cnt[(threadIdx.x >> 6) * 8 + k], stamp_acc[k]);
-#endif
 
     if (NEXT) {  // hand this workgroup's share of the next count matrix over
         for (uint32_t i = threadIdx.x; i < a.g.num_regions * RADIX; i += WG) {
             const uint32_t c = s_jn[i];
-            if (c) atomicAdd(&a.jnext[i], (unsigned long long)c);
+            if (c)
+                __hip_atomic_fetch_add(reinterpret_cast<JT*>(a.jnext) + (blockIdx.x % J_REPL) * (a.g.num_regions * RADIX) + i, (JT)c,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+#ifdef RSX_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned long long stamp_end = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&a.dbg_cnt[(threadIdx.x >> 6) * 8 + k], stamp_acc[k]);
+    if (threadIdx.x == 0) {  // prologue / epilogue of the workgroup: [64] roll call, [65] cursors, [66] flush, [67] workgroups
+        atomicAdd(&a.dbg_cnt[64], stamp_called - stamp_entry);
+        atomicAdd(&a.dbg_cnt[65], stamp_loop - stamp_called);
+        atomicAdd(&a.dbg_cnt[66], stamp_end - stamp_prev);
+        atomicAdd(&a.dbg_cnt[67], 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------ segmented copy --

@@ -8,7 +8,7 @@
 
 namespace rsxh {
 template int launch_hist<RSX_ES>(rsx_ctx*, const void*, const RegionGeom&, const rsx_layout*, uint32_t,
-                                 unsigned long long*, hipStream_t);
+                                 unsigned long long*, unsigned long long*, bool, hipStream_t);
 template int launch_sweep<RSX_ES>(rsx_ctx*, const void*, void*, const RegionGeom&, const rsx_layout*, uint32_t,
                                   const unsigned long long*, unsigned long long*, unsigned long long*, int, hipStream_t);
 template int launch_segcopy<RSX_ES>(rsx_ctx*, const void*, void*, const uint64_t*, const uint64_t*, const uint64_t*,

@@ -23,19 +23,19 @@
 namespace rsxh {
 using namespace rsx;
 
-// aux block layout (one hipMalloc, zeroed at creation).  A sort zeroes [OFF_J0, OFF_ZERO_END)
-// with ONE memset before its count kernel: the first two count matrices and every pass's
-// ticket / roll-call words.  The third count matrix is zeroed by the first sweep.
+// aux block layout (one hipMalloc, zeroed at creation).  A sort zeroes, with ONE memset before its
+// count kernel, every pass's ticket / roll-call words and the part of count matrix 0 it uses; the
+// count kernel clears matrix 1, the first sweep matrix 2 (and so on round the three).
+// A count matrix is kept in J_REPL replicas (rsx_device.hpp): [J_REPL][num_regions][256] u64.
 constexpr int MAX_PASSES = 16;                                                   // u128 keys
-constexpr size_t J_BYTES = (size_t)MAX_REGIONS * RADIX * sizeof(uint64_t);       // one count matrix
-constexpr size_t TICKET_WORDS = MAX_REGIONS + 2;                                 // per pass: tickets + roll call
-constexpr size_t OFF_J0 = 0;
+constexpr size_t J_BYTES = (size_t)J_REPL * MAX_REGIONS * RADIX * sizeof(uint64_t);  // one count matrix, all replicas
+constexpr size_t TICKET_WORDS = ROLL_SHARDS + (size_t)ROLL_SHARD_COUNT * ROLL_SHARD_STRIDE;  // per pass (rsx_device.hpp)
+constexpr size_t OFF_TICKETS = 0;                                                // [MAX_PASSES][TICKET_WORDS] u32
+constexpr size_t OFF_J0 = ((MAX_PASSES * TICKET_WORDS * 4 + 255) / 256) * 256;
 constexpr size_t OFF_J1 = OFF_J0 + J_BYTES;
-constexpr size_t OFF_TICKETS = OFF_J1 + J_BYTES;                                 // [MAX_PASSES][TICKET_WORDS] u32
-constexpr size_t OFF_ZERO_END = OFF_TICKETS + ((MAX_PASSES * TICKET_WORDS * 4 + 255) / 256) * 256;
-constexpr size_t OFF_J2 = OFF_ZERO_END;
-constexpr size_t OFF_BASE = OFF_J2 + J_BYTES;                                    // [MAX_REGIONS][256] cursors (API paths)
-constexpr size_t OFF_FLAGS = OFF_BASE + J_BYTES;                                 // self-test verdicts
+constexpr size_t OFF_J2 = OFF_J1 + J_BYTES;
+constexpr size_t OFF_BASE = OFF_J2 + J_BYTES;                                    // scratch of the context self-tests
+constexpr size_t OFF_FLAGS = OFF_BASE + 4096;                                    // self-test verdicts
 constexpr size_t OFF_DBG = OFF_FLAGS + 256;                                      // 16 waves x 8 diagnostic counters
 constexpr size_t AUX_BYTES = OFF_DBG + 1024;
 
@@ -230,10 +230,12 @@ inline uint32_t* tickets_of(rsx_ctx* c, uint32_t pass) {
 inline uint32_t* flags_of(rsx_ctx* c) { return reinterpret_cast<uint32_t*>(c->aux + OFF_FLAGS); }
 
 // ---- per-element-size launchers (defined in rsx_launch_impl.hpp, instantiated in rsx_es.hip) ----
-// count phase of a first pass: J[r][v] for `digit` over the input regions (J zeroed by the caller)
+// count phase of a first pass: J[rep][r][v] for `digit` over the input regions (J zeroed by the caller);
+// jclear: a second count matrix to clear on the way (or null); clear_status: zero the tile status words of
+// the sweep that follows (first half of the workspace)
 template <int ES>
 int launch_hist(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_layout* L, uint32_t digit,
-                unsigned long long* J, hipStream_t st);
+                unsigned long long* J, unsigned long long* jclear, bool clear_status, hipStream_t st);
 // one sweep pass.  J: this pass's count matrix; jnext: accumulated for the next pass (or null);
 // jzero: matrix to clear for the pass after next (or null); xf: bit 0 = map signed/float keys on
 // load (first pass), bit 1 = map back on store (last pass)

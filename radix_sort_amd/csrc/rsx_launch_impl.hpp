@@ -12,24 +12,27 @@ namespace rsxh {
 // ---- count phase of a first pass: J[r][v] for `digit` over the input regions ------------------
 template <int ES, bool FLT>
 int launch_hist_t(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_layout* L, uint32_t digit,
-                  unsigned long long* J, hipStream_t st) {
+                  unsigned long long* J, unsigned long long* jclear, bool clear_status, hipStream_t st) {
     const uint64_t per_block = 512ull * 16;
+    // the status words of the sweep that follows (its first half of the workspace) are zeroed by this kernel
+    const uint64_t zero16_n = clear_status ? status_rows(g, ES) * RADIX * (status32(g) ? 4u : 8u) / 16u : 0u;
     uint64_t bpr = ((1ull << g.region_shift) + per_block - 1) / per_block;
     const uint64_t cap = ((uint64_t)ctx->num_cu * RSX_HIST_BLOCKS_PER_CU + g.num_regions - 1) / g.num_regions;
     if (bpr > cap) bpr = cap;
     if (bpr == 0) bpr = 1;
     LaunchTimer lt(ctx, RSX_PROF_HIST, st);
     hipLaunchKernelGGL((rsx_hist_kernel<ES, FLT>), dim3((uint32_t)(bpr * g.num_regions)), dim3(512), 0, st,
-                       static_cast<const Elem<ES>*>(src), g, make_spec(L, digit), (uint32_t)bpr, J);
+                       static_cast<const Elem<ES>*>(src), g, make_spec(L, digit), (uint32_t)bpr, J, jclear, status32(g) ? 1u : 0u,
+                       static_cast<uint4*>(ctx->status), zero16_n);
     RSX_HIP(hipGetLastError());
     return RSX_OK;
 }
 template <int ES>
 int launch_hist(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_layout* L, uint32_t digit,
-                unsigned long long* J, hipStream_t st) {
+                unsigned long long* J, unsigned long long* jclear, bool clear_status, hipStream_t st) {
     if (L->key_kind == RSX_KEY_FLOAT || (L->key_kind == RSX_KEY_SIGNED && digit + 1 == L->key_bytes))
-        return launch_hist_t<ES, true>(ctx, src, g, L, digit, J, st);
-    return launch_hist_t<ES, false>(ctx, src, g, L, digit, J, st);
+        return launch_hist_t<ES, true>(ctx, src, g, L, digit, J, jclear, clear_status, st);
+    return launch_hist_t<ES, false>(ctx, src, g, L, digit, J, jclear, clear_status, st);
 }
 
 // ---- scatter phase: one sweep pass -------------------------------------------------------------
@@ -61,11 +64,11 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
     constexpr int SWEEP_WG = wg_for(ES);
     constexpr int TILE = SWEEP_WG * KPT;
     const uint64_t rows = status_rows(g, ES);
-    // Status words alternate between the two halves of the workspace.  Only the first pass of a
-    // sort zeroes its half with a memset; every pass zeroes, tile by tile, the half of the next.
+    // Status words alternate between the two halves of the workspace.  The first half is zeroed by the
+    // count kernel that precedes the first sweep; every pass zeroes, tile by tile, the half of the next.
     char* const half[2] = {static_cast<char*>(ctx->status), static_cast<char*>(ctx->status) + ctx->status_bytes};
     const uint32_t which = ctx->pass_index & 1u;
-    if (ctx->pass_index == 0) RSX_HIP(hipMemsetAsync(half[0], 0, (size_t)rows * RADIX * sizeof(S), st));
+    (void)rows;
     SweepArgs a;
     a.status_clean = ctx->pass_last ? nullptr : half[which ^ 1u];
     a.src = src;
@@ -74,7 +77,7 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
     a.J = J;
     a.status = half[which];
     a.tickets = tickets_of(ctx, ctx->pass_index);
-    a.prev_mode = ctx->pass_index ? tickets_of(ctx, ctx->pass_index - 1) + MAX_REGIONS + 1 : nullptr;
+    a.prev_mode = ctx->pass_index ? tickets_of(ctx, ctx->pass_index - 1) + ROLL_SHARDS + 1 : nullptr;
     a.jnext = jnext;
     a.jzero = jzero;
     a.error = ctx->host_err_dev;

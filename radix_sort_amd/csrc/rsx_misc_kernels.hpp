@@ -10,10 +10,11 @@ namespace rsx {
 // building blocks hand to the multi-GPU driver, and what the one-byte counting path expands.
 // The prefix phase proper (mod.rs:110-120) runs inside the sweep kernel's prologue.
 __global__ __launch_bounds__(256) void rsx_totals_kernel(const unsigned long long* __restrict__ J,
-                                                         uint32_t num_regions, uint64_t* __restrict__ counts_out) {
+                                                         uint32_t num_regions, uint64_t* __restrict__ counts_out, uint32_t j32) {
     const uint32_t tid = threadIdx.x;
     uint64_t c = 0;
-    for (uint32_t r = 0; r < num_regions; ++r) c += J[r * RADIX + tid];
+    for (uint32_t r = 0; r < (uint32_t)J_REPL * num_regions; ++r)  // all replicas, all regions
+        c += j32 ? (uint64_t)reinterpret_cast<const uint32_t*>(J)[r * RADIX + tid] : (uint64_t)J[r * RADIX + tid];
     counts_out[tid] = c;
 }
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B timing of library variants on ONE box: tools/ab.sh "variant[@RSX_DEBUG] ..." "workload ..."
 # (variants: radix_sort_amd/lib/v/NAME.so; two interleaved rounds to expose drift)
-for round in 1 2; do
+for round in $(seq 1 ${AB_ROUNDS:-2}); do
 for vv in $1; do
   v=${vv%%@*}; dbg=0; [[ "$vv" == *@* ]] && dbg=${vv#*@}
   echo "== $vv (round $round)"

@@ -6,7 +6,7 @@ ctx = rs.default_context(0)
 L = _lib.load()
 L.rsx_debug_counters.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
 key = sys.argv[1] if len(sys.argv) > 1 else "u32"
-d = rs.PRIMITIVES[key]; n = 1 << 28
+d = rs.PRIMITIVES[key]; n = 1 << int(os.environ.get('LG', '28'))
 x = torch.empty(n * d.elem_bytes, dtype=torch.uint8, device="cuda"); tmp = torch.empty_like(x)
 out = (ctypes.c_ulonglong * 128)()
 names = ["ticket+barrier", "load+match", "rank+barrier", "count/scan/offsets", "lds-scatter+barrier", "lookback+barrier", "writeout+barrier"]
@@ -23,3 +23,5 @@ for it in range(2):
         tot = sum(o[k] for k in range(7))
         tot += o[7]
         print(f"wave {w}: load-wait {o[7]/ntile:6.0f} | " + " | ".join(f"{names[k][:14]} {o[k]/ntile:6.0f}" for k in range(7)), f"| total {tot/ntile:.0f}")
+    wgs = max(1, out[67])
+    print(f"per workgroup: roll call {out[64]/wgs:6.0f} | cursors {out[65]/wgs:6.0f} | epilogue (flush) {out[66]/wgs:6.0f} | workgroups/launch {wgs/d.key_bytes:.0f} | tiles {ntile/d.key_bytes:.0f}")
