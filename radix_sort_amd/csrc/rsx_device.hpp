@@ -407,6 +407,9 @@ constexpr uint32_t SWEEP_OPT_RANK_CHECK = 8u;    // cross-check one round of ato
 #ifndef RSX_MINW
 #define RSX_MINW 6
 #endif
+#ifndef RSX_LB_WINDOW
+#define RSX_LB_WINDOW 1  // look-back words requested per round trip: 2 / 4 / 8 measured +0.4 / +1.9 / +5.7 % per 256M-key sort
+#endif
 #ifndef RSX_START_STAGGER
 #define RSX_START_STAGGER 224
 #endif
@@ -803,6 +806,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
     };
 #ifdef RSX_STAMPS
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long lbs_hops = 0, lbs_spins = 0, lbs_cycles = 0, lbs_tiles = 0;  // look-back of digit 0 (thread 0)
     unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
     const unsigned long long stamp_loop = stamp_prev;
 #endif
@@ -1038,29 +1042,52 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         // 0.485-0.498 ms per pass at every step spacing tried) and no different on 8- and 16-byte elements --
         // the waves that walk stall inside the reorder on each word, and the other four wait for them at
         // the barrier either way.
-        S lb_pend = 0;         // the word of the hop in flight
+        constexpr int LBW = RSX_LB_WINDOW;  // words requested per round trip (the chain's earlier tiles, nearest first)
+        S lb_pend[LBW];        // the words in flight
+        uint32_t lb_n = 0;     // how many of them were requested
         S lb_excl = 0;         // sum of the predecessors' counts so far (region-relative: fits S)
         uint32_t lb_left = 0;  // predecessors not yet summed (tiles kt-1 .. 0 of the chain); 0 = walk finished
+#pragma unroll
+        for (int i = 0; i < LBW; ++i) lb_pend[i] = 0;
+        // request up to `want` words starting with the nearest predecessor not yet summed
+        auto lb_request = [&](uint32_t want) __attribute__((always_inline)) {
+            const uint32_t dist = kt - lb_left + 1u;  // 1 = the tile right before this one
+            lb_n = lb_left < want ? lb_left : want;
+#pragma unroll
+            for (int i = 0; i < LBW; ++i)
+                if ((uint32_t)i < lb_n)
+                    lb_pend[i] = __hip_atomic_load(&status[stat_row - (uint64_t)(dist + (uint32_t)i) * RADIX + tid], __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+        };
         if ((EARLY_HOP || RSX_LB_OVERLAP) && tid < RADIX && kt > 0) {
             lb_left = kt;
-            lb_pend = __hip_atomic_load(&status[stat_row - RADIX + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lb_request(1u);  // early: only the nearest (the words behind it are worth more when read later)
         }
-        // one step of the walk: take the word in flight, request the next.  false = that word was still empty.
+        // one step of the walk: take the words in flight (in order, up to the first empty one), request the next
+        // window.  false = the first word was still empty.
         auto lb_step = [&]() __attribute__((always_inline)) -> bool {
             if (lb_left == 0) return true;
-            const uint32_t f = (uint32_t)(lb_pend >> Status<S>::SHIFT);
-            if (f != 0) {
-                lb_excl += (S)(lb_pend & Status<S>::MASK);
-                lb_left = f == 2 ? 0u : lb_left - 1u;
+            bool progressed = false, stalled = false;
+#pragma unroll
+            for (int i = 0; i < LBW; ++i) {
+                if ((uint32_t)i < lb_n && !stalled && lb_left != 0) {
+                    const uint32_t f = (uint32_t)(lb_pend[i] >> Status<S>::SHIFT);
+                    if (f != 0) {
+                        lb_excl += (S)(lb_pend[i] & Status<S>::MASK);
+                        lb_left = f == 2 ? 0u : lb_left - 1u;
+                        progressed = true;
+                    } else {
+                        stalled = true;
+                    }
+                }
             }
             if (lb_left == 0) {
                 const uint32_t real = (tid == 255) ? tcount - pad : tcount;
                 publish(&status[stat_row + tid], ((S)2 << Status<S>::SHIFT) | (S)((lb_excl + (S)real) & Status<S>::MASK));
             } else {
-                lb_pend = __hip_atomic_load(&status[stat_row - (uint64_t)(kt - lb_left + 1u) * RADIX + tid], __ATOMIC_RELAXED,
-                                            __HIP_MEMORY_SCOPE_AGENT);
+                lb_request((uint32_t)LBW);
             }
-            return f != 0;
+            return progressed;
         };
         // exclusive scan of tcount over the 256 digits -> start of each digit's run in the tile
         uint32_t incl = tcount;
@@ -1117,11 +1144,21 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         if (tid < RADIX) {
             if (!(EARLY_HOP || RSX_LB_OVERLAP) && kt > 0) {  // nothing requested yet
                 lb_left = kt;
-                lb_pend = __hip_atomic_load(&status[stat_row - RADIX + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lb_request((uint32_t)LBW);
             }
             uint32_t spins = 0;
+#ifdef RSX_STAMPS
+            const unsigned long long lbs_t0 = __builtin_amdgcn_s_memtime();
+            if (tid == 0 && kt > 0) ++lbs_tiles;
+#endif
             while (lb_left != 0) {
+#ifdef RSX_STAMPS
+                if (tid == 0) ++lbs_hops;
+#endif
                 if (!lb_step()) {
+#ifdef RSX_STAMPS
+                    if (tid == 0) ++lbs_spins;
+#endif
                     if (++spins > (1u << 22)) {  // bounded: never hang the device
                         __hip_atomic_store(a.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         break;
@@ -1129,6 +1166,9 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
+#ifdef RSX_STAMPS
+            if (tid == 0 && kt > 0) lbs_cycles += __builtin_amdgcn_s_memtime() - lbs_t0;
+#endif
             // element index of LDS slot 0 if it belonged to this digit's run (wrap-safe in u64)
             s_base[tid] = rbase + (uint64_t)lb_excl - (uint64_t)tstart;
             if (prefetch && RSX_PREFETCH_ALL == 1) issue_next();
@@ -1261,6 +1301,10 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         atomicAdd(&a.dbg_cnt[65], stamp_loop - stamp_called);
         atomicAdd(&a.dbg_cnt[66], stamp_end - stamp_prev);
         atomicAdd(&a.dbg_cnt[67], 1ull);
+        atomicAdd(&a.dbg_cnt[68], lbs_hops);    // look-back of digit 0: words looked at (the early hop excluded when it was ready),
+        atomicAdd(&a.dbg_cnt[69], lbs_spins);   // of which still empty,
+        atomicAdd(&a.dbg_cnt[70], lbs_cycles);  // cycles in the walk after the reorder,
+        atomicAdd(&a.dbg_cnt[71], lbs_tiles);   // tiles with a predecessor
     }
 #endif
 }

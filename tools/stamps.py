@@ -25,3 +25,5 @@ for it in range(2):
         print(f"wave {w}: load-wait {o[7]/ntile:6.0f} | " + " | ".join(f"{names[k][:14]} {o[k]/ntile:6.0f}" for k in range(7)), f"| total {tot/ntile:.0f}")
     wgs = max(1, out[67])
     print(f"per workgroup: roll call {out[64]/wgs:6.0f} | cursors {out[65]/wgs:6.0f} | epilogue (flush) {out[66]/wgs:6.0f} | workgroups/launch {wgs/d.key_bytes:.0f} | tiles {ntile/d.key_bytes:.0f}")
+    lt = max(1, out[71])
+    print(f"look-back of digit 0 per tile: {out[68]/lt:.2f} words looked at, {out[69]/lt:.2f} of them empty, {out[70]/lt:.0f} cycles in the walk")
