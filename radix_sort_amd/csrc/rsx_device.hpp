@@ -315,14 +315,13 @@ __global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restric
 #pragma unroll
         for (int u = 0; u < UNR; ++u)
             if (i + u * stride < nvec) {
-#if RSX_HIST_NT
-                if constexpr (VEC > 1) {
-                    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                if constexpr (RSX_HIST_NT != 0 && sizeof(Pack) == 16 && alignof(Pack) >= 16) {  // streaming 16-byte loads
+                    typedef uint32_t v4u __attribute__((ext_vector_type(4)));  // (12-, 24-byte elements in pieces: +1 %, left plain)
                     const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(vsrc + i + u * stride));
                     __builtin_memcpy(&p[u], &v, 16);
-                } else
-#endif
+                } else {
                     p[u] = vsrc[i + u * stride];
+                }
             }
 #pragma unroll
         for (int u = 0; u < UNR; ++u)
