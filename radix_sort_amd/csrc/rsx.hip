@@ -198,15 +198,13 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
     if (counting_path) {
         // u8 / i8: the element is its digit, so the 256 counts ARE the sorted array (same bytes as
         // the pass + copy-back of mod.rs:121-174 would leave): write the runs, skip scatter and copy
-        uint64_t* totals = reinterpret_cast<uint64_t*>(J_of(ctx, 1));
-        rc = launch_totals(ctx, geom, J_of(ctx, 0), totals, st);
-        if (rc) return rc;
         LaunchTimer lt(ctx, RSX_PROF_OTHER, st);
-        const uint64_t chunks = (n + 15) / 16;
-        uint64_t blocks = (chunks + 255) / 256;
+        const uint64_t steps = ((n + 15) / 16 + 255) / 256;  // a block writes 256 chunks of 16 bytes per step
+        uint64_t blocks = steps;
         if (blocks > (uint64_t)ctx->num_cu * 16) blocks = (uint64_t)ctx->num_cu * 16;
         hipLaunchKernelGGL(rsx_expand_bytes_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, static_cast<uint8_t*>(d_data),
-                           (uint64_t)n, totals, L->key_kind == RSX_KEY_SIGNED ? 0x80u : 0u);
+                           (uint64_t)n, J_of(ctx, 0), geom.num_regions, status32(geom) ? 1u : 0u,
+                           L->key_kind == RSX_KEY_SIGNED ? 0x80u : 0u);
         RSX_HIP(hipGetLastError());
         return RSX_OK;
     }

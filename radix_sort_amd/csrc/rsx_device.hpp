@@ -237,6 +237,7 @@ constexpr int MAX_REGIONS = 32;
 // 64-byte line serialise at the memory side (~12 ns each): with one matrix, 512 workgroups flushing 2048
 // counters each queued 512 deep on every line at the end of a pass (measured: 13 us per workgroup).
 constexpr int J_REPL = 8;
+static_assert(J_REPL == 8, "readers unroll the replica rows by 8");
 // Per-pass control words: [0, MAX_REGIONS) per-region tile tickets (dynamic mode), then the roll call:
 // ROLL_DONE counts complete shards, ROLL_MODE is the verdict, and ROLL_SHARD_COUNT arrival counters each
 // on a line of its own (workgroup b arrives at shard b % 8: 64 arrivals per line instead of 512 on one).

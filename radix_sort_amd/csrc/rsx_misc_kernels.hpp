@@ -13,8 +13,14 @@ __global__ __launch_bounds__(256) void rsx_totals_kernel(const unsigned long lon
                                                          uint32_t num_regions, uint64_t* __restrict__ counts_out, uint32_t j32) {
     const uint32_t tid = threadIdx.x;
     uint64_t c = 0;
-    for (uint32_t r = 0; r < (uint32_t)J_REPL * num_regions; ++r)  // all replicas, all regions
-        c += j32 ? (uint64_t)reinterpret_cast<const uint32_t*>(J)[r * RADIX + tid] : (uint64_t)J[r * RADIX + tid];
+    for (uint32_t r0 = 0; r0 < (uint32_t)J_REPL * num_regions; r0 += 8) {  // all replicas, all regions; 8 loads in flight
+        uint64_t part[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k)
+            part[k] = j32 ? (uint64_t)reinterpret_cast<const uint32_t*>(J)[(r0 + k) * RADIX + tid] : (uint64_t)J[(r0 + k) * RADIX + tid];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) c += part[k];
+    }
     counts_out[tid] = c;
 }
 
@@ -23,13 +29,28 @@ __global__ __launch_bounds__(256) void rsx_totals_kernel(const unsigned long lon
 // the 256 counts written out as runs (counting sort: one read of the data, one write, no scatter).
 // `counts` are by mapped digit (the count kernel maps signed keys); byte = mapped value ^ xor_mask.
 __global__ __launch_bounds__(256) void rsx_expand_bytes_kernel(uint8_t* __restrict__ dst, uint64_t n,
-                                                               const uint64_t* __restrict__ counts,
-                                                               uint32_t xor_mask) {
+                                                               const unsigned long long* __restrict__ J, uint32_t num_regions,
+                                                               uint32_t j32, uint32_t xor_mask) {
     __shared__ uint64_t start[RADIX + 1];
     __shared__ uint64_t wsum[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint64_t x = counts[tid];
-    const uint64_t c = x;
+    // the 256 digit totals of the count matrix (all replicas, all regions): every block sums them itself
+    // (L2-resident, 64-128 independent loads per thread) -- no totals launch in between
+    uint64_t c = 0;
+    {
+        const uint32_t rows = (uint32_t)J_REPL * num_regions;
+        for (uint32_t r0 = 0; r0 < rows; r0 += 8) {
+            uint64_t part[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) {
+                const uint32_t r = r0 + k;  // rows is a multiple of 8 (J_REPL == 8)
+                part[k] = j32 ? (uint64_t)reinterpret_cast<const uint32_t*>(J)[r * RADIX + tid] : (uint64_t)J[r * RADIX + tid];
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) c += part[k];
+        }
+    }
+    uint64_t x = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const uint64_t y = __shfl_up(x, o);
@@ -44,25 +65,42 @@ __global__ __launch_bounds__(256) void rsx_expand_bytes_kernel(uint8_t* __restri
     __syncthreads();
     const bool wide = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;  // 16-byte stores need the alignment
     const uint64_t chunks = (n + 15) / 16;
-    for (uint64_t ch = (uint64_t)blockIdx.x * blockDim.x + tid; ch < chunks; ch += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t p0 = ch * 16;
-        uint32_t lo = 0, hi = RADIX;  // last v with start[v] <= p0
+    // last v with start[v] <= p
+    auto digit_at = [&](uint64_t p) {
+        uint32_t lo = 0, hi = RADIX;
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) / 2;
-            if (start[mid] <= p0) lo = mid;
+            if (start[mid] <= p) lo = mid;
             else hi = mid;
         }
-        uint32_t v = lo;
-        uint32_t w[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            while (v < RADIX - 1 && start[v + 1] <= p0 + k) ++v;  // empty digits are stepped over
-            w[k / 4] |= ((v ^ xor_mask) & 0xFFu) << (8 * (k % 4));
-        }
-        if (wide && p0 + 16 <= n) {
-            *reinterpret_cast<uint4*>(dst + p0) = make_uint4(w[0], w[1], w[2], w[3]);
+        return lo;
+    };
+    // a wave writes 64 consecutive chunks (1 KiB) per step; a run is n/256 bytes on average, so nearly every
+    // step lies inside ONE run: one search by the wave (all lanes read the same words: broadcasts), then splat
+    for (uint64_t base = ((uint64_t)blockIdx.x * 4 + wave) * 64; base < chunks; base += (uint64_t)gridDim.x * 4 * 64) {
+        const uint64_t ch = base + lane;
+        const uint64_t span0 = base * 16;
+        const uint32_t v0 = digit_at(span0);  // wave-uniform
+        uint32_t w[4];
+        const uint64_t p0 = ch * 16;
+        if (start[v0 + 1] >= span0 + 64 * 16) {  // wave-uniform: the whole span is digit v0
+            const uint32_t byte = (v0 ^ xor_mask) & 0xFFu;
+            w[0] = w[1] = w[2] = w[3] = byte * 0x01010101u;
         } else {
-            for (int k = 0; k < 16 && p0 + k < n; ++k) dst[p0 + k] = (uint8_t)(w[k / 4] >> (8 * (k % 4)));
+            uint32_t v = digit_at(p0);
+            w[0] = w[1] = w[2] = w[3] = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                while (v < RADIX - 1 && start[v + 1] <= p0 + k) ++v;  // empty digits are stepped over
+                w[k / 4] |= ((v ^ xor_mask) & 0xFFu) << (8 * (k % 4));
+            }
+        }
+        if (ch < chunks) {
+            if (wide && p0 + 16 <= n) {
+                *reinterpret_cast<uint4*>(dst + p0) = make_uint4(w[0], w[1], w[2], w[3]);
+            } else {
+                for (int k = 0; k < 16 && p0 + k < n; ++k) dst[p0 + k] = (uint8_t)(w[k / 4] >> (8 * (k % 4)));
+            }
         }
     }
 }
