@@ -103,9 +103,11 @@ enum {
     RSX_OPT_MAX_REGIONS = 6,   /* 0 (default: 8 or 16 by element size) .. 32 look-back chains per pass */
     RSX_OPT_HOT_LANES = 7,     /* 2..65 (default 16): lanes sharing a digit that mark a tile as skewed */
     RSX_OPT_VERBOSE = 8,       /* 1: launch geometry and self-test verdicts on stderr (also env RSX_VERBOSE=1) */
-    RSX_OPT_RANK_CHECK = 9     /* 1: in every tile, one round of LDS-atomic ranks is cross-checked against the
+    RSX_OPT_RANK_CHECK = 9,    /* 1: in every tile, one round of LDS-atomic ranks is cross-checked against the
                                   ballot-derived ranks (the property rsx_lds_order_kernel tests on an idle device,
                                   here under the real sweeps' LDS contention); a mismatch makes rsx_ctx_check fail */
+    RSX_OPT_SMALL_SORT = 10    /* 1 (default): arrays of at most one tile (14336 4-byte, 6144 8-byte, 2560 16-byte
+                                  elements ...) are sorted by ONE launch of one workgroup; 0: by the general path */
 };
 int rsx_ctx_set_option(rsx_ctx *ctx, int option, uint64_t value);
 enum {

@@ -132,6 +132,9 @@ int hist_dispatch(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_
                   unsigned long long* J, unsigned long long* jclear, bool clear_status, hipStream_t st) {
     RSX_DISPATCH_ES(L->elem_bytes, launch_hist, ctx, src, g, L, digit, J, jclear, clear_status, st)
 }
+int small_dispatch(rsx_ctx* ctx, void* data, size_t n, const rsx_layout* L, hipStream_t st) {
+    RSX_DISPATCH_ES(L->elem_bytes, launch_small_sort, ctx, data, n, L, st)
+}
 int sweep_dispatch(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L,
                    uint32_t digit, const unsigned long long* J, unsigned long long* jnext, unsigned long long* jzero,
                    int xf, hipStream_t st) {
@@ -189,10 +192,13 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
     Enqueue enq(ctx, st);
     const uint32_t D = L->key_bytes;  // T::NUMBER_OF_DIGITS
     const RegionGeom geom = make_geom(ctx, n, L->elem_bytes);
+    const bool counting_path = L->elem_bytes == 1 && !(ctx->options & OPT_GENERAL_BYTES);  // no sweep follows
+    // at most one tile: all D passes in one launch of one workgroup (rsx_small_kernel.hpp)
+    if (!counting_path && n <= tile_elems((int)L->elem_bytes) && !(ctx->options & OPT_NO_SMALL_SORT))
+        return small_dispatch(ctx, d_data, n, L, st);
     // count phase of pass 0 (mod.rs:90-109); later passes are counted by the sweep before them
     rc = zero_counters(ctx, geom, st);
     if (rc) return rc;
-    const bool counting_path = L->elem_bytes == 1 && !(ctx->options & OPT_GENERAL_BYTES);  // no sweep follows
     rc = hist_dispatch(ctx, d_data, geom, L, 0, J_of(ctx, 0), D > 1 ? J_of(ctx, 1) : nullptr, !counting_path, st);
     if (rc) return rc;
     if (counting_path) {
@@ -384,6 +390,10 @@ int rsx_ctx_set_option(rsx_ctx* ctx, int option, uint64_t value) try {
             return RSX_OK;
         case RSX_OPT_RANK_CHECK:
             flag(OPT_RANK_CHECK, value != 0);
+            return RSX_OK;
+        case RSX_OPT_SMALL_SORT:
+            if (value > 1) return fail(ctx, RSX_ERR_ARG, "RSX_OPT_SMALL_SORT: 0 or 1");
+            flag(OPT_NO_SMALL_SORT, value == 0);
             return RSX_OK;
         default:
             return fail(ctx, RSX_ERR_ARG, "unknown option");

@@ -11,6 +11,7 @@ template int launch_hist<RSX_ES>(rsx_ctx*, const void*, const RegionGeom&, const
                                  unsigned long long*, unsigned long long*, bool, hipStream_t);
 template int launch_sweep<RSX_ES>(rsx_ctx*, const void*, void*, const RegionGeom&, const rsx_layout*, uint32_t,
                                   const unsigned long long*, unsigned long long*, unsigned long long*, int, hipStream_t);
+template int launch_small_sort<RSX_ES>(rsx_ctx*, void*, size_t, const rsx_layout*, hipStream_t);
 template int launch_segcopy<RSX_ES>(rsx_ctx*, const void*, void*, const uint64_t*, const uint64_t*, const uint64_t*,
                                     uint32_t, hipStream_t);
 }  // namespace rsxh

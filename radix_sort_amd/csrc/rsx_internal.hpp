@@ -49,6 +49,7 @@ enum : uint32_t {
     OPT_GENERAL_BYTES = 1u << 5,   // one-byte elements through the general pass
     OPT_VERBOSE = 1u << 6,
     OPT_RANK_CHECK = 1u << 7,      // cross-check atomic ranks against ballots on real tiles (tests)
+    OPT_NO_SMALL_SORT = 1u << 8,   // arrays of at most one tile through the general path too
 };
 
 }  // namespace rsxh
@@ -243,6 +244,9 @@ template <int ES>
 int launch_sweep(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L, uint32_t digit,
                  const unsigned long long* J, unsigned long long* jnext, unsigned long long* jzero, int xf,
                  hipStream_t st);
+// arrays of at most one tile (tile_elems(ES)): the whole sort in one launch of one workgroup, in place
+template <int ES>
+int launch_small_sort(rsx_ctx* ctx, void* data, size_t n, const rsx_layout* L, hipStream_t st);
 template <int ES>
 int launch_segcopy(rsx_ctx* ctx, const void* src, void* dst, const uint64_t* so, const uint64_t* dof,
                    const uint64_t* len, uint32_t nseg, hipStream_t st);

@@ -2,6 +2,7 @@
 // rsx_internal.hpp.  Included only by rsx_es.hip, which instantiates them for ONE element size.
 #pragma once
 #include "rsx_internal.hpp"
+#include "rsx_small_kernel.hpp"
 
 #ifndef RSX_HIST_BLOCKS_PER_CU
 #define RSX_HIST_BLOCKS_PER_CU 8
@@ -182,6 +183,32 @@ int launch_sweep(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, 
                  hipStream_t st) {
     if (status32(g)) return launch_sweep_x<ES, uint32_t>(ctx, src, dst, g, L, digit, J, jnext, jzero, xf, st);
     return launch_sweep_x<ES, uint64_t>(ctx, src, dst, g, L, digit, J, jnext, jzero, xf, st);
+}
+
+// ---- arrays of at most one tile: all passes in one launch of one workgroup ----------------------
+template <int ES>
+int launch_small_sort(rsx_ctx* ctx, void* data, size_t n, const rsx_layout* L, hipStream_t st) {
+    constexpr int KPT = kpt_for(ES);
+    static_assert(wg_for(ES) == 512, "the one-tile kernel is written for 512 threads");
+    if (n == 0 || n > (size_t)512 * KPT || L->key_bytes > 16) return fail(ctx, RSX_ERR_INTERNAL, "launch_small_sort: size out of range");
+    SmallArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.data = data;
+    a.n = (uint32_t)n;
+    a.passes = L->key_bytes;
+    a.rank_atomic = (ctx->rank_atomic && !(ctx->options & OPT_BALLOT_RANKS)) ? 1u : 0u;
+    a.map_keys = L->key_kind == RSX_KEY_UNSIGNED ? 0u : 1u;
+    for (uint32_t d = 0; d < L->key_bytes; ++d) {
+        a.spec[d] = make_spec(L, d);
+        a.spec[d].flip = 0;  // the kernel sees mapped keys: plain digits
+    }
+    a.xf = make_xform(L);
+    const size_t lds = (size_t)512 * KPT * ES + 8 * RADIX * sizeof(uint32_t) + 64;
+    auto kern = rsx_small_sort_kernel<ES, KPT>;
+    LaunchTimer lt(ctx, RSX_PROF_OTHER, st);
+    hipLaunchKernelGGL(kern, dim3(1), dim3(512), lds, st, a);
+    RSX_HIP(hipGetLastError());
+    return RSX_OK;
 }
 
 template <int ES>

@@ -288,7 +288,8 @@ ALT_PATHS = [("OPT_TILE_SCHEDULE", 1, "ticketed tiles instead of the static roll
              ("OPT_BYTE_COUNTING", 0, "one-byte elements through the general pass instead of the counting path"),
              ("OPT_MAX_REGIONS", 1, "one look-back chain over all tiles"),
              ("OPT_MAX_REGIONS", 32, "32 look-back chains"),
-             ("OPT_HOT_LANES", 2, "every tile treated as skewed")]
+             ("OPT_HOT_LANES", 2, "every tile treated as skewed"),
+             ("OPT_SMALL_SORT", 0, "arrays of at most one tile through the general path")]
 
 
 @pytest.mark.parametrize("opt,value,what", ALT_PATHS)
@@ -301,7 +302,10 @@ def test_alternative_kernel_paths_match(rs, torch, orc, opt, value, what):
     for t, n, dist in (("u32", 3000001, "uniform"), ("(u64,u64)", 700001, "zipf"), ("f32", 1500000, "uniform"),
                        ("u8", 5000000, "uniform"), ("i8", 3000001, "zipf"), ("(u8,[u8;7])", 2000003, "two"),
                        ("(u32,u32)", 1000001, "step16"), ("(i16,u16)", 1234567, "equal"), ("u64", 2000001, "lowbyte"),
-                       ("(u32,[u8;8])", 500009, "zipf")):
+                       ("(u32,[u8;8])", 500009, "zipf"),
+                       # at most one tile: the one-launch kernel (or, with OPT_SMALL_SORT = 0, the general path on a tiny input)
+                       ("u32", 1000, "uniform"), ("i64", 6144, "zipf"), ("(u64,u64)", 2560, "equal"), ("f32", 14336, "uniform"),
+                       ("(u8,[u8;7])", 777, "two"), ("u16", 3, "uniform"), ("(u128,u128)", 1535, "lowbyte")):
         d = _digits(rs, t)
         raw = util.make_input(t, n, dist, seed=31)
         x = torch.from_numpy(raw.copy()).cuda()
