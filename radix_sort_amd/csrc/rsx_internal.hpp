@@ -150,6 +150,9 @@ struct LaunchTimer {
 #ifndef RSX_KPT4
 #define RSX_KPT4 28
 #endif
+#ifndef RSX_KPT2
+#define RSX_KPT2 RSX_KPT4  // 1- and 2-byte elements
+#endif
 #ifndef RSX_WG4
 #define RSX_WG4 512
 #endif
@@ -168,7 +171,7 @@ struct LaunchTimer {
 #ifndef RSX_WG8
 #define RSX_WG8 512
 #endif
-constexpr int kpt_for(int es) { return es <= 4 ? RSX_KPT4 : es == 8 ? RSX_KPT8 : es == 12 ? RSX_KPT12 : es == 16 ? RSX_KPT16 : RSX_KPT32; }
+constexpr int kpt_for(int es) { return es <= 2 ? RSX_KPT2 : es <= 4 ? RSX_KPT4 : es == 8 ? RSX_KPT8 : es == 12 ? RSX_KPT12 : es == 16 ? RSX_KPT16 : RSX_KPT32; }
 constexpr int wg_for(int es) { return es <= 4 ? RSX_WG4 : es == 8 ? RSX_WG8 : 512; }
 constexpr uint32_t tile_elems(int es) { return wg_for(es) * kpt_for(es); }
 
