@@ -106,7 +106,7 @@ enum {
     RSX_OPT_RANK_CHECK = 9,    /* 1: in every tile, one round of LDS-atomic ranks is cross-checked against the
                                   ballot-derived ranks (the property rsx_lds_order_kernel tests on an idle device,
                                   here under the real sweeps' LDS contention); a mismatch makes rsx_ctx_check fail */
-    RSX_OPT_SMALL_SORT = 10    /* 1 (default): arrays of at most one tile (14336 4-byte, 6144 8-byte, 2560 16-byte
+    RSX_OPT_SMALL_SORT = 10    /* 1 (default): arrays of at most one tile (14336 4-byte, 7168 8-byte, 2560 16-byte
                                   elements ...) are sorted by ONE launch of one workgroup; 0: by the general path */
 };
 int rsx_ctx_set_option(rsx_ctx *ctx, int option, uint64_t value);

@@ -144,8 +144,8 @@ struct LaunchTimer {
 // Keys per thread by element size.  Tiles need not be powers of two (the last tile of a region is
 // partial anyway); bigger tiles mean longer output runs per digit (fewer partial cache lines, the
 // memory system's real cost here) and fewer look-backs per key, as long as two or three workgroups
-// still fit a CU: u32 28 x 512 = 14336 keys (56 KiB), u64 12 x 512 (48 KiB), 16-byte 5 x 512 (40 KiB),
-// 12-byte 10 x 512 (60 KiB), 24/32-byte 3 x 512 (36/48 KiB).
+// still fit a CU: u32 28 x 512 = 14336 keys (56 KiB), u64 14 x 512 (56 KiB), 16-byte 5 x 512 (40 KiB),
+// 12-byte 10 x 512 (60 KiB), 24-byte 5 x 512 (60 KiB), 32-byte 3 x 512 (48 KiB).
 // Measured against 16 / 8 / 4: 1B u32 117 -> 136, 1B u64 32 -> 34.9, 128M (u64,u64) 17.3 -> 18 Gkeys/s.
 #ifndef RSX_KPT4
 #define RSX_KPT4 28
@@ -157,7 +157,7 @@ struct LaunchTimer {
 #define RSX_WG4 512
 #endif
 #ifndef RSX_KPT8
-#define RSX_KPT8 12
+#define RSX_KPT8 14  // 56 KiB tiles, still two workgroups per CU with 16 regions: 1B u64 30.8 -> 30.15 ms, Zipf u64 -3.4 % (12: round 1)
 #endif
 #ifndef RSX_KPT16
 #define RSX_KPT16 5
@@ -168,10 +168,13 @@ struct LaunchTimer {
 #ifndef RSX_KPT32
 #define RSX_KPT32 3
 #endif
+#ifndef RSX_KPT24
+#define RSX_KPT24 5  // with 8 regions: 60 KiB tiles at two workgroups per CU: 2 GiB of (u64,[u64;2]) 8.34 -> 7.53 ms (3 x 512, 16 regions)
+#endif
 #ifndef RSX_WG8
 #define RSX_WG8 512
 #endif
-constexpr int kpt_for(int es) { return es <= 2 ? RSX_KPT2 : es <= 4 ? RSX_KPT4 : es == 8 ? RSX_KPT8 : es == 12 ? RSX_KPT12 : es == 16 ? RSX_KPT16 : RSX_KPT32; }
+constexpr int kpt_for(int es) { return es <= 2 ? RSX_KPT2 : es <= 4 ? RSX_KPT4 : es == 8 ? RSX_KPT8 : es == 12 ? RSX_KPT12 : es == 16 ? RSX_KPT16 : es == 24 ? RSX_KPT24 : RSX_KPT32; }
 constexpr int wg_for(int es) { return es <= 4 ? RSX_WG4 : es == 8 ? RSX_WG8 : 512; }
 constexpr uint32_t tile_elems(int es) { return wg_for(es) * kpt_for(es); }
 
@@ -184,7 +187,7 @@ inline RegionGeom make_geom(const rsx_ctx* ctx, uint64_t n, uint32_t es) {
     uint32_t k = log2u(tile_elems((int)es));
     if ((1ull << k) < tile_elems((int)es)) ++k;  // tiles need not be a power of two; regions are
     // the next pass's count matrix costs 1 KiB of LDS per region: 8 where the tile needs the room
-    const uint64_t cap = ctx->max_regions ? ctx->max_regions : (es == 8 || es > 16) ? 16 : 8;
+    const uint64_t cap = ctx->max_regions ? ctx->max_regions : (es == 8 || es == 32) ? 16 : 8;
     while (((n + (1ull << k) - 1) >> k) > cap) ++k;
     g.region_shift = k;
     g.num_regions = (uint32_t)((n + (1ull << k) - 1) >> k);

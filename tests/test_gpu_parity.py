@@ -304,7 +304,7 @@ def test_alternative_kernel_paths_match(rs, torch, orc, opt, value, what):
                        ("(u32,u32)", 1000001, "step16"), ("(i16,u16)", 1234567, "equal"), ("u64", 2000001, "lowbyte"),
                        ("(u32,[u8;8])", 500009, "zipf"),
                        # at most one tile: the one-launch kernel (or, with OPT_SMALL_SORT = 0, the general path on a tiny input)
-                       ("u32", 1000, "uniform"), ("i64", 6144, "zipf"), ("(u64,u64)", 2560, "equal"), ("f32", 14336, "uniform"),
+                       ("u32", 1000, "uniform"), ("i64", 7168, "zipf"), ("(u64,u64)", 2560, "equal"), ("f32", 14336, "uniform"),
                        ("(u8,[u8;7])", 777, "two"), ("u16", 3, "uniform"), ("(u128,u128)", 1535, "lowbyte")):
         d = _digits(rs, t)
         raw = util.make_input(t, n, dist, seed=31)

@@ -5,7 +5,7 @@ import torch, radix_sort_amd as rs
 ctx = rs.default_context(0)
 for key in ("u32", "u64"):
     d = rs.PRIMITIVES[key]
-    for n in (1 << 10, 1 << 12, rs.PRIMITIVES[key].elem_bytes == 4 and 14336 or 6144, 1 << 14, 1 << 16, 1 << 18, 1 << 20, 1 << 22, 1 << 24, 1 << 26, 1 << 28):
+    for n in (1 << 10, 1 << 12, rs.PRIMITIVES[key].elem_bytes == 4 and 14336 or 7168, 1 << 14, 1 << 16, 1 << 18, 1 << 20, 1 << 22, 1 << 24, 1 << 26, 1 << 28):
         lg = n.bit_length() - 1
         x = torch.empty(n * d.elem_bytes, dtype=torch.uint8, device="cuda"); tmp = torch.empty_like(x)
         reps = 20 if lg <= 22 else 5
