@@ -194,7 +194,7 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
     const RegionGeom geom = make_geom(ctx, n, L->elem_bytes);
     const bool counting_path = L->elem_bytes == 1 && !(ctx->options & OPT_GENERAL_BYTES);  // no sweep follows
     // at most one tile: all D passes in one launch of one workgroup (rsx_small_kernel.hpp)
-    if (!counting_path && n <= tile_elems((int)L->elem_bytes) && !(ctx->options & OPT_NO_SMALL_SORT))
+    if (!counting_path && n <= (size_t)512 * kpt_for((int)L->elem_bytes) && !(ctx->options & OPT_NO_SMALL_SORT))  // one 512-thread tile
         return small_dispatch(ctx, d_data, n, L, st);
     // count phase of pass 0 (mod.rs:90-109); later passes are counted by the sweep before them
     rc = zero_counters(ctx, geom, st);

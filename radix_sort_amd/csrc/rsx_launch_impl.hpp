@@ -189,7 +189,6 @@ int launch_sweep(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, 
 template <int ES>
 int launch_small_sort(rsx_ctx* ctx, void* data, size_t n, const rsx_layout* L, hipStream_t st) {
     constexpr int KPT = kpt_for(ES);
-    static_assert(wg_for(ES) == 512, "the one-tile kernel is written for 512 threads");
     if (n == 0 || n > (size_t)512 * KPT || L->key_bytes > 16) return fail(ctx, RSX_ERR_INTERNAL, "launch_small_sort: size out of range");
     SmallArgs a;
     std::memset(&a, 0, sizeof a);
