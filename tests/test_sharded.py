@@ -231,3 +231,16 @@ def test_one_exchange_hip_two_ranks_one_gpu(orc, tmp_path, tname, dist_name, siz
     lay = orc.Layout(*util.TYPES[tname])
     full = util.make_input(tname, sum(sizes), dist_name, seed=78)
     assert np.array_equal(got, orc.sort_parallel(full, lay, 4))
+
+
+@pytest.mark.gpu
+def test_rccl_backend_world1():
+    """The RCCL ("nccl") backend has never moved a byte between two GPUs here (one-GPU boxes).  With ONE rank it
+    still runs every collective call of the three schedules and of bench.py's cross-rank check through RCCL:
+    argument types, dtypes and split lists are accepted, results verified on the device."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_world1.py")
+    out = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600)
+    print(out.stdout[-2000:], out.stderr[-2000:])
+    assert out.returncode == 0 and "RCCL WORLD1 OK" in out.stdout
