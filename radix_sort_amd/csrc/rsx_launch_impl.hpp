@@ -90,7 +90,8 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
     a.opts = ((ctx->options & OPT_DYNAMIC_TILES) ? SWEEP_OPT_DYNAMIC : 0u) |
              ((ctx->options & OPT_NO_XCD_MAJOR) ? SWEEP_OPT_NO_XCD_MAJOR : 0u) |
              ((ctx->options & OPT_AGENT_STATUS) || !ctx->l2_local ? SWEEP_OPT_AGENT_STATUS : 0u) |
-             ((ctx->options & OPT_RANK_CHECK) ? SWEEP_OPT_RANK_CHECK : 0u);
+             ((ctx->options & OPT_RANK_CHECK) ? SWEEP_OPT_RANK_CHECK : 0u) |
+             ((uint64_t)g.n * ES <= (2ull << 30) ? SWEEP_OPT_PREREAD : 0u);  // measured: a gain up to 2 GiB of data, a loss at 4 GiB
     a.dbg = ctx->dbg;
     a.rank_atomic = (ctx->rank_atomic && !(ctx->options & OPT_BALLOT_RANKS)) ? 1u : 0u;
     a.hot_lanes = (ctx->options & OPT_ATOMIC_RANKS) ? 65u : ctx->hot_lanes;
