@@ -53,6 +53,24 @@ def test_edge_sizes_uniform(rs, torch, ctx, orc, t):
         assert np.array_equal(_gpu_sort(rs, torch, ctx, raw, d), orc.sort_parallel(raw, lay, 4)), (t, n)
 
 
+TILE_KEYS = {1: 28, 2: 28, 4: 28, 8: 14, 12: 10, 16: 5, 24: 5, 32: 3}  # keys per thread of the 512-thread tile, by element size
+
+
+@pytest.mark.parametrize("t", list(util.TYPES))
+def test_sizes_around_the_tile(rs, torch, ctx, orc, t):
+    """The one-launch kernel (n <= one tile), the general path right above it, and seeded random sizes up to three
+    tiles with seeded random distributions: every type, bytes compared with the oracle."""
+    d = _digits(rs, t)
+    lay = orc.Layout(*util.TYPES[t])
+    tile = 512 * TILE_KEYS[d.elem_bytes]
+    rng = np.random.default_rng(4242 + d.elem_bytes + 100 * d.key_bytes)
+    sizes = [tile - 1, tile, tile + 1, 2 * tile - 1, 2 * tile, 2 * tile + 1] + [int(x) for x in rng.integers(1, 3 * tile, size=10)]
+    for i, n in enumerate(sizes):
+        dist = util.DISTS[int(rng.integers(0, len(util.DISTS)))]
+        raw = util.make_input(t, n, dist, seed=9000 + i)
+        assert np.array_equal(_gpu_sort(rs, torch, ctx, raw, d), orc.sort_parallel(raw, lay, 3)), (t, n, dist)
+
+
 @pytest.mark.parametrize("t", list(util.TYPES))
 @pytest.mark.parametrize("dist", util.DISTS)
 def test_distributions(rs, torch, ctx, orc, t, dist):
