@@ -111,9 +111,20 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
     }
     // persistent workgroups; correctness does not need them co-resident (a workgroup only
     // ever waits for tiles whose tickets were drawn earlier, by workgroups already running)
-    const uint64_t total_tiles = (g.n + TILE - 1) / TILE + g.num_regions;
+    // tiles of region r: every region ends with a tile of its own (partial unless the region length is a multiple
+    // of the tile), so the total is NOT ceil(n / TILE)
+    const uint32_t NR = g.num_regions;
+    const uint64_t region_len = 1ull << g.region_shift;
+    auto tiles_of = [&](uint32_t r) -> uint64_t {
+        const uint64_t beg = (uint64_t)r << g.region_shift;
+        const uint64_t len = g.n - beg < region_len ? g.n - beg : region_len;
+        return (len + TILE - 1) / TILE;
+    };
+    uint64_t real_tiles = 0;
+    for (uint32_t r = 0; r < NR; ++r) real_tiles += tiles_of(r);
     uint64_t grid = (uint64_t)ctx->num_cu * occ;
-    if (grid > total_tiles) grid = total_tiles;
+    if (grid > real_tiles) grid = real_tiles;
+    if (grid < NR) grid = NR;
 #ifdef RSX_TUNING
     if (const char* o = std::getenv("RSX_OCC")) {
         const long v = std::atol(o);
@@ -122,14 +133,10 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
 #endif
     if (grid > 0xFFFFu) grid = 0xFFFFu;  // wg_first entries are 16 bit
     {   // static mode: workgroups per region, proportional to the region's tile count, >= 1 each
-        const uint32_t NR = g.num_regions;
-        const uint64_t tpr = tiles_per_region(g, ES);
-        const uint64_t real_tiles = (g.n + TILE - 1) / TILE;
         uint64_t cum = 0;
         for (uint32_t r = 0; r < NR; ++r) {
             a.wg_first[r] = (uint16_t)(cum * grid / real_tiles);
-            const uint64_t left = real_tiles - cum;
-            cum += left < tpr ? left : tpr;
+            cum += tiles_of(r);
         }
         a.wg_first[NR] = (uint16_t)grid;
         for (uint32_t r = 0; r < NR; ++r)  // at least one workgroup per region
@@ -147,7 +154,7 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
             for (uint32_t r = 0; r < NR; ++r)
                 if (a.wg_first[r] / (grid / 8) == (a.wg_first[r + 1] - 1u) / (grid / 8)) a.local_mask |= 1u << r;
     }
-    if (ctx->options & OPT_VERBOSE) std::fprintf(stderr, "[rsx] sweep ES=%d NEXT=%d occ=%d grid=%llu lds=%zu tiles=%llu regions=%u\n", ES, (int)NEXT, occ, (unsigned long long)grid, lds, (unsigned long long)total_tiles, g.num_regions);
+    if (ctx->options & OPT_VERBOSE) std::fprintf(stderr, "[rsx] sweep ES=%d NEXT=%d occ=%d grid=%llu lds=%zu tiles=%llu regions=%u\n", ES, (int)NEXT, occ, (unsigned long long)grid, lds, (unsigned long long)real_tiles, g.num_regions);
     LaunchTimer lt(ctx, RSX_PROF_SWEEP, st);
     hipLaunchKernelGGL(kern, dim3((uint32_t)grid), dim3(SWEEP_WG), lds, st, a);
     RSX_HIP(hipGetLastError());
