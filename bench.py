@@ -6,7 +6,10 @@ input already resident in HBM.  K steps sort K different pre-generated batches, 
 every timed sort sees unsorted data and generation stays outside the timed region.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1: either under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`
+  (one rank per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or typed plainly: the parent
+  process then starts exactly that launcher as a child BEFORE it touches the GPU, relays rank 0's JSON line and
+  exits with the launcher's return code.
 
 Prints ONE JSON line on rank 0 (contract in the round prompt): `value` = Gkeys/s of the
 whole job; `roofline` = dominant kernel (rsx_sweep_kernel, one launch = one pass,
@@ -46,7 +49,8 @@ WORKLOADS = {
     "reversed-256m-u32": ("u32", 28, "reversed", 0.0, "256M u32 keys in reverse order"),
     "pairs-128m-u64u64": ("(u64,u64)", 27, "uniform", 0.0, "128M (u64,u64) pairs (reference bench type, main.rs:123)"),
 }
-EXTRA_DEFAULT = ["target-1b-u32", "c3-1b-u64", "zipf-256m-u32", "step16-256m-u32"]
+HEADLINE = "c3-1b-u64"  # the largest single-GPU configuration in BASELINE.json's configs (configs[2])
+EXTRA_DEFAULT = ["target-1b-u32", "c2-256m-u32", "c4-slice-512m-u32", "zipf-256m-u32", "step16-256m-u32", "zipf-256m-u64", "c5-slice-128m-pairs-zipf"]
 
 
 def digits_for(rs, t):
@@ -104,6 +108,7 @@ def run_single(rs, torch, ctx, wl, steps, warmup, seed0=0x5EED0000, profile=True
         done += k
     if check:
         ctx.check()
+    lp = ctx.get_info(rs.INFO_LAST_PASSES)  # tile schedule of the last timed sort's passes
     # untimed sanity: last batch is sorted and is a permutation of its input
     out = torch.zeros(3, dtype=torch.int64, device="cuda")
     ctx.verify_device(bufs[k - 1].data_ptr(), n, d, out.data_ptr(), stream)
@@ -119,6 +124,8 @@ def run_single(rs, torch, ctx, wl, steps, warmup, seed0=0x5EED0000, profile=True
         "algorithmic_gbps": D * 2 * n * d.elem_bytes / ms / 1e6,
         "frac_of_hbm_peak": D * 2 * n * d.elem_bytes / ms / 1e6 / HBM_PEAK_GBPS,
     }
+    res["paths"] = {"rank_atomic": ctx.get_info(rs.INFO_RANK_ATOMIC), "l2_local": ctx.get_info(rs.INFO_L2_LOCAL),
+                    "static_tiles": f"{(lp >> 8) & 0xFF}/{lp & 0xFF}", "placement_verified": f"{(lp >> 16) & 0xFF}/{lp & 0xFF}"}
     if profile and prof_tot["sweep"][1]:
         sw_ms = prof_tot["sweep"][0] / prof_tot["sweep"][1]
         res["sweep_ms_per_launch"] = sw_ms
@@ -129,34 +136,79 @@ def run_single(rs, torch, ctx, wl, steps, warmup, seed0=0x5EED0000, profile=True
     return res
 
 
-def cpu_baseline(t_name, n_full, target_seconds=15.0):
-    """The oracle (port of mod.rs:61-176) on this host's cores; protocol of main.rs:26-44:
-    mean of 5 runs on fresh data, timed region = the sort call incl. temp alloc + page touch."""
+def _host_batch(np, n, es, kb, salt):
+    """n elements of uniform keys (payload 0, like KeyUniform, distr.rs:42-52) at memory speed: a 2^22-element
+    random block repeated under a different odd multiplier per repetition (a bijection of the 64-bit words: the keys
+    stay uniform and every repetition differs)."""
+    from concurrent.futures import ThreadPoolExecutor
+    words = n * es // 8
+    blk = 1 << 22
+    base = np.random.default_rng(salt).integers(0, 1 << 63, size=min(blk, words), dtype=np.uint64)
+    out = np.empty(words, dtype=np.uint64)
+
+    def fill(i):  # numpy releases the GIL inside the multiply: the blocks are filled (and first-touched) in parallel
+        off = i * blk
+        m = min(blk, words - off)
+        np.multiply(base[:m], np.uint64(2 * (salt * 4099 + i) + 0x9E3779B97F4A7C15), out=out[off:off + m])
+    with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as pool:
+        list(pool.map(fill, range((words + blk - 1) // blk)))
+    raw = out.view(np.uint8)
+    if es != kb:
+        raw.reshape(n, es)[:, kb:] = 0
+    return raw
+
+
+def cpu_baseline(t_name, n_full, budget_seconds=30.0):
+    """The oracle (port of mod.rs:61-176) on this host's cores; protocol of main.rs:26-44: mean of 5 runs on fresh
+    data, timed region = the sort call incl. temp alloc + page touch.  Runs at the configuration's own n when five
+    sorts of it fit `budget_seconds` (rate calibrated on 2^26 keys), else on the largest power of two that does."""
     import numpy as np
     from oracle import oracle
     oracle.build()
     es, kb = {"u32": (4, 4), "u64": (8, 8), "(u64,u64)": (16, 8), "(u32,u32)": (8, 4)}[t_name]
     lay = oracle.Layout(es, 0, kb, 0)
     cores = os.cpu_count() or 1
-    rng = np.random.default_rng(1)
 
-    def one(n):
-        raw = rng.integers(0, 256, size=n * es, dtype=np.uint8)
-        if es != kb:
-            raw.reshape(n, es)[:, kb:] = 0  # payload 0, like KeyUniform (distr.rs:42-52)
+    def one(n, salt):
+        raw = _host_batch(np, n, es, kb, salt)
         t0 = time.perf_counter()
         oracle.sort_parallel_inplace(raw, lay, cores)
         return time.perf_counter() - t0
 
-    n_cal = 1 << 22
-    rate = n_cal / one(n_cal)  # keys/s
-    n = int(min(n_full, max(1 << 22, rate * target_seconds / 5)))
+    n_cal = min(n_full, 1 << 26)
+    one(1 << 22, 99)  # thread pools, page cache
+    rate = n_cal / one(n_cal, 100)  # keys/s
+    n = int(min(n_full, max(1 << 22, rate * budget_seconds / 5)))
     n = 1 << (n.bit_length() - 1)
-    runs = [one(n) for _ in range(5)]
+    runs = [one(n, 1 + i) for i in range(5)]
     mean = sum(runs) / len(runs)
+    own = ", the configuration's own n" if n == n_full else ""
     return {"value": n / mean / 1e9, "unit": "Gkeys/s", "cores": cores, "kind": "port",
-            "sample": f"{n} {t_name} uniform keys (2^{n.bit_length()-1}), mean of 5 runs, {cores} threads, "
+            "sample": f"{n} {t_name} uniform keys (2^{n.bit_length()-1}{own}), mean of 5 runs, {cores} threads, "
                       f"timed like main.rs:32-34 (temp alloc + page touch inside)"}
+
+
+def cpu_ladder(logn=24, t_name="(u32,u32)", runs=3):
+    """the reference's optimisation ladder radix_sort0..5 (mod.rs:178-571, restated in the oracle) timed on
+    THIS host's cores, protocol of main.rs:26-44.  Bounded: 2^24 pairs, 3 runs per rung."""
+    import numpy as np
+    from oracle import oracle
+    oracle.build()
+    es, kb = {"u32": (4, 4), "u64": (8, 8), "(u32,u32)": (8, 4), "(u64,u64)": (16, 8)}[t_name]
+    lay = oracle.Layout(es, 0, kb, 0)
+    n, cores = 1 << logn, os.cpu_count() or 1
+    names = ["radix_sort0 (single thread)", "radix_sort1 (thread per digit)", "radix_sort2 (chunk per thread)",
+             "radix_sort3 (+ page-touched scratch)", "radix_sort4 (+ work pool)", "radix_sort5 (+ 96-element write buffers)"]
+    rungs = {}
+    for v, name in enumerate(names):
+        tot = 0.0
+        for r in range(runs):
+            raw = _host_batch(np, n, es, kb, 7 + r)
+            t0 = time.perf_counter()
+            oracle.sort_variant_inplace(raw, lay, cores, v)
+            tot += time.perf_counter() - t0
+        rungs[name] = {"seconds": tot / runs, "gkeys_per_s": n / (tot / runs) / 1e9}
+    return {"sample": f"{n} {t_name} uniform keys, mean of {runs} runs", "cores": cores, "kind": "port", "rungs": rungs}
 
 
 def pmc_traffic(workload):
@@ -175,9 +227,12 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
-                    help="default: c2-256m-u32 (configs[1]) at N=1; c4-slice-512m-u32 per GPU at N>1 (configs[3]: 2^32 keys at N=8)")
+                    help="default: c3-1b-u64 (configs[2], the largest single-GPU configuration) at N=1 and per GPU at N>1 (weak scaling)")
     ap.add_argument("--extra", default=",".join(EXTRA_DEFAULT),
                     help="comma list of further workloads measured with the same --steps/--warmup and reported under 'extra' at N=1; '' = none")
+    ap.add_argument("--extra-sharded", default="c4-slice-512m-u32",
+                    help="N>1: comma list of further per-GPU workloads reported under 'extra' (default: the configs[3] slice, "
+                         "2^29 u32 per GPU = 4B keys at N=8); '' = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N>1 collectives: nccl (= RCCL over xGMI, the measured path); gloo only to rehearse the N>1 code "
@@ -189,9 +244,23 @@ def main():
     ap.add_argument("--chunks", type=int, default=4,
                     help="--exchange first: ranges the exchange is cut into so that the local sort of one range runs while "
                          "the next ones are on the links (1 = no overlap)")
+    ap.add_argument("--cpu-ladder", action="store_true",
+                    help="N=1: also time the reference's CPU ladder radix_sort0..5 (oracle restatement) on this host: extra.cpu_ladder")
     args = ap.parse_args()
     if args.workload is None:
-        args.workload = "c2-256m-u32" if args.gpus <= 1 else "c4-slice-512m-u32"
+        args.workload = HEADLINE  # N > 1: the same configuration per GPU (weak scaling of the N = 1 line)
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # typed plainly: start the N ranks as fresh children (nothing in this process has touched the GPU: no
+        # torch.cuda call, no radix_sort_amd context) and pass their verdict on
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))).returncode)
 
     import torch
     import radix_sort_amd as rs
@@ -200,7 +269,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE)")
     if args.backend == "gloo":
         local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
@@ -231,6 +300,7 @@ def main():
                 "traffic": pmc_traffic(args.workload),
                 "traffic_note": "HBM bytes per launch, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, separate passes), profiles/pmc_traffic.json",
             },
+            "paths": res["paths"],
         }
         extra = {}
         for wl in [w for w in args.extra.split(",") if w and w != args.workload]:
@@ -242,8 +312,11 @@ def main():
                 extra[wl]["sweep_frac_of_hbm_peak"] = (r.get("sweep_gbps") or 0.0) / HBM_PEAK_GBPS
                 extra[wl]["steps"] = args.steps
                 extra[wl]["sweep_traffic_bytes_per_launch"] = pmc_traffic(wl)
+                extra[wl]["paths"] = r["paths"]
             except Exception as e:  # noqa: BLE001  (an extra must never kill the headline)
                 extra[wl] = {"error": repr(e)}
+        if args.cpu_ladder:
+            extra["cpu_ladder"] = cpu_ladder()
         if extra:
             line["extra"] = extra
         if not args.no_cpu_baseline:
@@ -251,7 +324,7 @@ def main():
         print(json.dumps(line), flush=True)
         return
 
-    # ---- N > 1: one slice per rank, per-pass bucket exchange over RCCL ---------------------
+    # ---- N > 1: one slice per rank; weak scaling of the N = 1 headline (same type and n per GPU) --------------
     import torch.distributed as dist
     from radix_sort_amd.sharded import ShardedRadixSort
     if args.backend == "nccl":
@@ -259,86 +332,96 @@ def main():
     else:
         dist.init_process_group("gloo")
     sorter = ShardedRadixSort()
-    nbytes = n * d.elem_bytes
     stream = torch.cuda.current_stream().cuda_stream
-    pool = args.steps
-    bufs = [torch.empty(nbytes, dtype=torch.uint8, device="cuda") for _ in range(pool)]
-    n_per_rank = [n] * world
-
-    def fill(i, b):
-        ctx.generate_device(b.data_ptr(), n, d, gen_id(rs, gen), 0x5EED0000 + i, param, rank * n, stream)
-
-    run = {"first": lambda b: sorter.sort_exchange_first(b, d, n_per_rank, chunks=args.chunks),
-           "one": lambda b: sorter.sort_one_exchange(b, d, n_per_rank),
-           "per-pass": lambda b: sorter.sort(b, d, n_per_rank)}[args.exchange]
-    wbuf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-    for i in range(args.warmup):
-        fill(1000 + i, wbuf)
-        run(wbuf)
-    for i in range(pool):
-        fill(i, bufs[i])
-    # multiset checksum of the last batch before it is sorted (sum over ranks, compared after)
-    out = torch.zeros(3, dtype=torch.int64, device="cuda")
-    ctx.verify_device(bufs[-1].data_ptr(), n, d, out.data_ptr(), stream)
-    sum_before = out[1:2].clone()
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        run(bufs[i])
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
     cdev = "cuda" if args.backend == "nccl" else "cpu"
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cdev)
-    dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    # untimed global check of the last batch: (a) every rank's slice in order and stable, (b) the multiset
-    # unchanged (checksums all-reduced), (c) order across rank boundaries: last key of rank r <= first key of r+1
-    ctx.verify_device(bufs[-1].data_ptr(), n, d, out.data_ptr(), stream)
-    torch.cuda.synchronize()
-    assert out[0].item() == 0 and out[2].item() == 0, f"rank {rank}: slice not sorted / not stable: {out.tolist()}"
-    sums = torch.stack([sum_before[0], out[1]]).to(cdev)
-    dist.all_reduce(sums)  # int64 wrap-around == the checksum's arithmetic mod 2^64
-    assert sums[0].item() == sums[1].item(), "multiset checksum changed across the exchange"
-    es = d.elem_bytes
-    edge = torch.cat([bufs[-1][:es], bufs[-1][(n - 1) * es:n * es]]).cpu()
 
-    def mapped(e):  # order-preserving integer of one element's key (radix_digits.rs via RadixDigits.get_digit)
-        return sum(d.get_digit(bytes(e.tolist()), i) << (8 * i) for i in range(d.key_bytes))
-    def limbs(k):  # 128-bit key as four 32-bit limbs, most significant first (int64 tensors carry them)
-        return [(k >> s) & 0xFFFFFFFF for s in (96, 64, 32, 0)]
-    mine = torch.tensor(limbs(mapped(edge[:es])) + limbs(mapped(edge[es:])), dtype=torch.int64)
-    allk = [torch.zeros(8, dtype=torch.int64, device=cdev) for _ in range(world)]
-    dist.all_gather(allk, mine.to(cdev))
-    keys = []
-    for gathered in allk:
-        a = [int(v) for v in gathered.cpu().tolist()]
-        keys.append((a[0] << 96 | a[1] << 64 | a[2] << 32 | a[3], a[4] << 96 | a[5] << 64 | a[6] << 32 | a[7]))
-    for r in range(world - 1):
-        assert keys[r][1] <= keys[r + 1][0], f"order broken between rank {r} and {r + 1}"
-    ms = el.item() * 1e3 / args.steps
-    total = n * world
+    def run_sharded(wl):
+        t, logn, gen, param, desc = WORKLOADS[wl]
+        d = digits_for(rs, t)
+        n = 1 << logn
+        nbytes = n * d.elem_bytes
+        free, _total = torch.cuda.mem_get_info()
+        share = max(1, min(world, world // max(1, torch.cuda.device_count())))  # gloo rehearsal: ranks sharing a device
+        pool = max(1, min(args.steps, int((free * 0.8 / share - 4 * nbytes) // nbytes)))
+        bufs = [torch.empty(nbytes, dtype=torch.uint8, device="cuda") for _ in range(pool)]
+        n_per_rank = [n] * world
+
+        def fill(i, b):
+            ctx.generate_device(b.data_ptr(), n, d, gen_id(rs, gen), 0x5EED0000 + i, param, rank * n, stream)
+
+        run = {"first": lambda b: sorter.sort_exchange_first(b, d, n_per_rank, chunks=args.chunks),
+               "one": lambda b: sorter.sort_one_exchange(b, d, n_per_rank),
+               "per-pass": lambda b: sorter.sort(b, d, n_per_rank)}[args.exchange]
+        for i in range(args.warmup):
+            fill(1000 + i, bufs[0])
+            run(bufs[0])
+        done, elapsed = 0, 0.0
+        while done < args.steps:  # pool-sized rounds (pool == steps unless memory is short)
+            k = min(pool, args.steps - done)
+            for i in range(k):
+                fill(done + i, bufs[i])
+            sum_before = sorter.checksum(bufs[k - 1], d)  # multiset checksum of the round's last batch, before
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(k):
+                run(bufs[i])
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            elapsed += time.perf_counter() - t0
+            done += k
+        el = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        # untimed global check of the last batch (ShardedRadixSort.verify): every rank's slice in order and stable,
+        # the multiset unchanged (checksums all-reduced), the last key of rank r <= the first key of rank r + 1
+        sorter.verify(bufs[k - 1], d, sum_before)
+        del bufs
+        torch.cuda.empty_cache()
+        ms = el.item() * 1e3 / args.steps
+        total = n * world
+        return {"workload": wl, "desc": desc, "type": t, "n_total": total, "n_per_gpu": n, "d": d, "gen": gen, "ms": ms,
+                "gkeys_per_s": total / ms / 1e6, "algorithmic_gbps": d.key_bytes * 2 * total * d.elem_bytes / ms / 1e6,
+                "branch": sorter.last_branch}
+
+    r = run_sharded(args.workload)
+    extra = {}
+    for wl in [w for w in args.extra_sharded.split(",") if w and w != args.workload]:
+        try:
+            x = run_sharded(wl)
+            extra[wl] = {"type": x["type"], "n_keys": x["n_total"], "n_keys_per_gpu": x["n_per_gpu"], "ms_per_sort": x["ms"],
+                         "gkeys_per_s": x["gkeys_per_s"], "frac_of_hbm_peak": x["algorithmic_gbps"] / (HBM_PEAK_GBPS * world),
+                         "exchange_branch": x["branch"], "steps": args.steps}
+        except AssertionError:
+            raise  # a wrong result is never swallowed
+        except Exception as e:  # noqa: BLE001
+            extra[wl] = {"error": repr(e)}
     if rank == 0:
+        d, t = r["d"], r["type"]
         line = {
             "metric": "Gkeys/sec (u32)" if t == "u32" else f"Gkeys/sec ({t})",
-            "value": total / ms / 1e6, "unit": "Gkeys/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "value": r["gkeys_per_s"], "unit": "Gkeys/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": r["ms"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u%d" % (8 * d.key_bytes) if t[0] in "u(" else t, "data": "synthetic",
-            "config": {"workload": f"{args.workload} per GPU x {world}: {desc}", "n_keys": total,
-                       "n_keys_per_gpu": n, "elem_bytes": d.elem_bytes, "passes": d.key_bytes, "radix_bits": 8,
-                       "generator": gen,
-                       "exchange": {"first": "partition by the top digit + all-gather(256 x u64) + exact cuts inside boundary buckets + "
-                                             "ONE all-to-all-v in %d batches, each range sorted while the next is on the links" % args.chunks,
+            "config": {"workload": f"{args.workload} per GPU x {world}: {r['desc']}", "n_keys": r["n_total"],
+                       "n_keys_per_gpu": r["n_per_gpu"], "elem_bytes": d.elem_bytes, "passes": d.key_bytes, "radix_bits": 8,
+                       "generator": r["gen"],
+                       "exchange": {"first": "partition by the top digit in %d sub-ranges + all-gather(256 x u64) + exact cuts inside boundary "
+                                             "buckets (device-side search, one D2H) + ONE all-to-all-v in %d batches, each range sorted while "
+                                             "the next is on the links" % (args.chunks, args.chunks),
                                     "one": "local sort + 256-way splitter search (1 all-reduce per digit) + ONE all-to-all-v + local sort",
                                     "per-pass": "per-pass all-gather(256 x u64) + all-to-all-v"}[args.exchange] +
                                    (" (RCCL)" if args.backend == "nccl" else " (gloo, host-staged: rehearsal only)"),
+                       "exchange_branch": r["branch"],
                        "verified": "slices sorted and stable, multiset checksum all-reduced, rank-boundary keys in order"},
-            "roofline": {"bound": "hbm", "achieved": d.key_bytes * 2 * total * d.elem_bytes / ms / 1e6,
+            "roofline": {"bound": "hbm", "achieved": r["algorithmic_gbps"],
                          "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
-                         "frac": d.key_bytes * 2 * total * d.elem_bytes / ms / 1e6 / (HBM_PEAK_GBPS * world),
+                         "frac": r["algorithmic_gbps"] / (HBM_PEAK_GBPS * world),
                          "traffic": None, "note": "whole-job algorithmic bytes / wall time (exchange included)"},
         }
+        if extra:
+            line["extra"] = extra
         print(json.dumps(line), flush=True)
     dist.destroy_process_group()
 

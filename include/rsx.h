@@ -114,7 +114,11 @@ enum {
     RSX_INFO_RANK_ATOMIC = 1, /* 1 if the LDS atomic ordering self-test passed on this device */
     RSX_INFO_L2_LOCAL = 2,    /* 1 if the same-XCD hand-off self-test passed on this device */
     RSX_INFO_NUM_CU = 3,
-    RSX_INFO_DEVICE = 4
+    RSX_INFO_DEVICE = 4,
+    RSX_INFO_LAST_PASSES = 5  /* which tile schedule the passes of the context's LAST sort ran with (waits for it):
+                                 bits 0-7 sweep passes launched (0: one-launch or counting path), bits 8-15 of them
+                                 with static tiles (the roll call succeeded), bits 16-23 of them with the XCD
+                                 placement verified (status words of single-XCD chains stay in L2) */
 };
 int rsx_ctx_get_info(rsx_ctx *ctx, int what, uint64_t *out);
 /* Per-launch timing with HIP events on the launch stream (measurement only).

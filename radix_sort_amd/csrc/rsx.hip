@@ -193,6 +193,7 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
     const uint32_t D = L->key_bytes;  // T::NUMBER_OF_DIGITS
     const RegionGeom geom = make_geom(ctx, n, L->elem_bytes);
     const bool counting_path = L->elem_bytes == 1 && !(ctx->options & OPT_GENERAL_BYTES);  // no sweep follows
+    ctx->last_sort_passes = 0;
     // at most one tile: all D passes in one launch of one workgroup (rsx_small_kernel.hpp)
     if (!counting_path && n <= (size_t)512 * kpt_for((int)L->elem_bytes) && !(ctx->options & OPT_NO_SMALL_SORT))  // one 512-thread tile
         return small_dispatch(ctx, d_data, n, L, st);
@@ -215,6 +216,7 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
         return RSX_OK;
     }
     // pass loop with ping-pong (mod.rs:84-89); the prefix phase (mod.rs:110-120) is the prologue of each sweep
+    ctx->last_sort_passes = D;
     for (uint32_t d = 0; d < D; ++d) {
         const void* src = (d % 2 == 0) ? d_data : d_tmp;
         void* dst = (d % 2 == 0) ? d_tmp : d_data;
@@ -310,6 +312,7 @@ int rsx_ctx_destroy(rsx_ctx* ctx) try {
         if (ctx->shard_q) (void)hipFree(ctx->shard_q);
         if (ctx->shard_out) (void)hipFree(ctx->shard_out);
         if (ctx->shard_hist) (void)hipFree(ctx->shard_hist);
+        if (ctx->shard_host) (void)hipHostFree(ctx->shard_host);
         if (ctx->shard_stream) (void)hipStreamDestroy(ctx->shard_stream);
         for (int k = 0; k < RSX_PROF_KINDS; ++k)
             for (auto& e : ctx->prof_pending[k]) ctx->prof_free.push_back(e);
@@ -415,6 +418,20 @@ int rsx_ctx_get_info(rsx_ctx* ctx, int what, uint64_t* out) try {
         case RSX_INFO_L2_LOCAL: *out = ctx->l2_local ? 1 : 0; return RSX_OK;
         case RSX_INFO_NUM_CU: *out = (uint64_t)ctx->num_cu; return RSX_OK;
         case RSX_INFO_DEVICE: *out = (uint64_t)ctx->device; return RSX_OK;
+        case RSX_INFO_LAST_PASSES: {
+            *out = 0;
+            if (!ctx->aux || ctx->last_sort_passes == 0) return RSX_OK;
+            if (ctx->busy) RSX_HIP(hipEventSynchronize(ctx->last_event));
+            uint64_t stat = 0, placed = 0;
+            for (uint32_t p = 0; p < ctx->last_sort_passes && p < (uint32_t)MAX_PASSES; ++p) {
+                uint32_t mode = 0;  // the roll call's verdict word: 1 static, 3 static + placement verified, 2 / 0 tickets
+                RSX_HIP(hipMemcpy(&mode, tickets_of(ctx, p) + ROLL_MODE, sizeof mode, hipMemcpyDeviceToHost));
+                stat += (mode == 1u || mode == 3u) ? 1u : 0u;
+                placed += mode == 3u ? 1u : 0u;
+            }
+            *out = (uint64_t)ctx->last_sort_passes | (stat << 8) | (placed << 16);
+            return RSX_OK;
+        }
         default: return fail(ctx, RSX_ERR_ARG, "unknown info id");
     }
 } catch (...) {

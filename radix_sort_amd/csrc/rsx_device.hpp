@@ -288,7 +288,7 @@ __global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restric
     __syncthreads();
     const uint32_t r = blockIdx.x / blocks_per_region;
     const uint32_t sub = blockIdx.x % blocks_per_region;
-    const uint64_t begin = (uint64_t)r << g.region_shift;  // a multiple of the tile size: 16-byte aligned
+    const uint64_t begin = (uint64_t)r << g.region_shift;
     uint64_t end = begin + (1ull << g.region_shift);
     if (end > g.n) end = g.n;
     auto count = [&](const Elem<ES>& e) {
@@ -307,8 +307,15 @@ __global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restric
     struct alignas(VEC > 1 ? 16 : alignof(Elem<ES>)) Pack {
         Elem<ES> e[VEC];
     };
-    const uint64_t nvec = (end - begin) / VEC;
-    const Pack* vsrc = reinterpret_cast<const Pack*>(src + begin);
+    // The C-ABI only asks for element alignment (and the multi-GPU drivers pass interior pointers): the elements
+    // ahead of the first 16-byte boundary are counted one by one, like the tail.
+    uint64_t head = 0;
+    if constexpr (VEC > 1) {
+        head = ((16u - (uint32_t)(reinterpret_cast<uintptr_t>(src + begin) & 15u)) & 15u) / ES;
+        if (head > end - begin) head = end - begin;
+    }
+    const uint64_t nvec = (end - begin - head) / VEC;
+    const Pack* vsrc = reinterpret_cast<const Pack*>(src + begin + head);
     const uint64_t stride = (uint64_t)blocks_per_region * blockDim.x;
     constexpr int UNR = RSX_HIST_UNROLL;
     for (uint64_t i = (uint64_t)sub * blockDim.x + tid; i < nvec; i += stride * UNR) {
@@ -331,9 +338,10 @@ __global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restric
                 for (int k = 0; k < VEC; ++k) count(p[u].e[k]);
             }
     }
-    if (VEC > 1 && sub == 0) {  // tail of the region (fewer than VEC elements)
-        const uint64_t i = begin + nvec * VEC + tid;
-        if (i < end) count(src[i]);
+    if (VEC > 1 && sub == 0) {  // head and tail of the region (fewer than VEC elements each): wave 0 / wave 1
+        if (tid < head) count(src[begin + tid]);
+        const uint64_t t0 = begin + head + nvec * VEC;
+        if (tid >= 64 && t0 + (tid - 64) < end) count(src[t0 + (tid - 64)]);
     }
     __syncthreads();
     if (tid < RADIX) {

@@ -79,6 +79,7 @@ struct rsx_ctx {
     int num_cu = 256;
     uint32_t pass_index = 0;   // of the sweep being launched within its sort (selects the status half, J rotation)
     bool pass_last = true;     // no pass follows: nothing to clean
+    uint32_t last_sort_passes = 0;  // sweep passes of the last sort (RSX_INFO_LAST_PASSES)
     bool rank_atomic = false;  // LDS atomic ordering self-test passed (set when the workspace is first made)
     bool l2_local = false;     // same-XCD hand-off self-test passed: chains may keep status words in their L2
     uint32_t hot_lanes = 16;

@@ -165,6 +165,7 @@ class ShardedRadixSort:
         import os
         self.timing = os.environ.get("RSX_SHARD_TIMING", "0") not in ("", "0") and self.rank == 0
         self._marks = []
+        self.last_branch = ""  # which exchange code ran in the last sort (bench.py records it)
 
     def _mark(self, label: str):
         if not self.timing:
@@ -489,6 +490,56 @@ class ShardedRadixSort:
                 dst.copy_(host)
             if csize[c] > 1:
                 be.sort(piece(x, coff[c], csize[c]), scratch[:int(csize[c]) * es], int(csize[c]), d)
+
+    # ---- verification of a sharded result (bench.py's N > 1 check and the tests share it) ----------------
+    def checksum(self, x, d: RadixDigits) -> int:
+        """Multiset checksum of this rank's slice (rsx_verify_device out[1]), taken BEFORE a sort."""
+        import torch
+        ctx = self.backend.ctx
+        n = x.numel() // d.elem_bytes
+        out = torch.zeros(3, dtype=torch.int64, device=x.device)
+        ctx.verify_device(x.data_ptr(), n, d, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        return int(out[1].item())
+
+    def verify(self, x, d: RadixDigits, checksum_before: int) -> None:
+        """Collective.  Raises AssertionError unless (a) every rank's slice is in order and stable (payload =
+        global index), (b) the multiset is unchanged (checksums summed over the ranks mod 2^64), (c) the last key of
+        rank r does not exceed the first key of rank r + 1 (empty slices are stepped over)."""
+        import torch
+        dist, ctx = self.dist, self.backend.ctx
+        es = d.elem_bytes
+        n = x.numel() // es
+        cdev = torch.device("cpu") if self.host_staged else x.device
+        out = torch.zeros(3, dtype=torch.int64, device=x.device)
+        ctx.verify_device(x.data_ptr(), n, d, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        v = out.cpu().tolist()
+        assert v[0] == 0 and v[2] == 0, f"rank {self.rank}: slice not sorted / not stable: {v}"
+        before = checksum_before - (1 << 64) if checksum_before >= (1 << 63) else checksum_before
+        sums = torch.tensor([before, v[1]], dtype=torch.int64).to(cdev)
+        dist.all_reduce(sums, group=self.group)  # int64 wrap-around == the checksum's arithmetic mod 2^64
+        assert sums[0].item() == sums[1].item(), "multiset checksum changed across the exchange"
+
+        def mapped(e):  # order-preserving integer of one element's key (radix_digits.rs via RadixDigits.get_digit)
+            return sum(d.get_digit(bytes(e.tolist()), i) << (8 * i) for i in range(d.key_bytes))
+
+        def limbs(k):  # 128-bit key as four 32-bit limbs, most significant first (int64 tensors carry them)
+            return [(k >> s) & 0xFFFFFFFF for s in (96, 64, 32, 0)]
+        if n:
+            edge = torch.cat([x[:es], x[(n - 1) * es:n * es]]).cpu()
+            mine = torch.tensor([1] + limbs(mapped(edge[:es])) + limbs(mapped(edge[es:])), dtype=torch.int64)
+        else:
+            mine = torch.zeros(9, dtype=torch.int64)
+        allk = [torch.zeros(9, dtype=torch.int64, device=cdev) for _ in range(self.world)]
+        dist.all_gather(allk, mine.to(cdev), group=self.group)
+        last = None
+        for r, gathered in enumerate(allk):
+            a = [int(t) for t in gathered.cpu().tolist()]
+            if not a[0]:
+                continue
+            first_k = a[1] << 96 | a[2] << 64 | a[3] << 32 | a[4]
+            last_k = a[5] << 96 | a[6] << 64 | a[7] << 32 | a[8]
+            assert last is None or last[1] <= first_k, f"order broken between rank {last[0]} and {r}"
+            last = (r, last_k)
 
     def sort(self, x, d: RadixDigits, n_per_rank: Optional[List[int]] = None):
         """x: this rank's slice as a contiguous uint8 tensor (n_local * elem_bytes).  In place."""

@@ -3,7 +3,7 @@
 # workloads.  usage: tools/profile_all.sh <round-tag> "<workloads for trace+traffic>" "<workloads for all PMC sets>"
 # Leaves gpurun_out/profiles_<tag>/<workload>_{kernel_stats.csv,bench.json,pmc.txt}; copy into profiles/.
 tag=$1; wls=$2; full=$3
-root=$GRAFT_REPO_ROOT; out=$root/gpurun_out/profiles_$tag; mkdir -p $out
+root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; [ -f "$root/bench.py" ] || { echo "no bench.py under $root"; exit 1; }; out=$root/gpurun_out/profiles_$tag; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $root
 for wl in $wls; do
   d=$out/trace_$wl; mkdir -p $d
