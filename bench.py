@@ -47,6 +47,8 @@ WORKLOADS = {
     "f64-128m": ("f64", 27, "uniform", 0.0, "128M f64 keys (uniform bit patterns)"),
     "sorted-256m-u32": ("u32", 28, "sorted", 0.0, "256M u32 keys already in order (key = index)"),
     "reversed-256m-u32": ("u32", 28, "reversed", 0.0, "256M u32 keys in reverse order"),
+    "u16-256m": ("u16", 28, "uniform", 0.0, "256M u16 uniform keys (2 passes)"),
+    "u8-256m": ("u8", 28, "uniform", 0.0, "256M u8 uniform keys (counting path)"),
     "pairs-128m-u64u64": ("(u64,u64)", 27, "uniform", 0.0, "128M (u64,u64) pairs (reference bench type, main.rs:123)"),
 }
 HEADLINE = "c3-1b-u64"  # the largest single-GPU configuration in BASELINE.json's configs (configs[2])

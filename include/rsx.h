@@ -106,8 +106,12 @@ enum {
     RSX_OPT_RANK_CHECK = 9,    /* 1: in every tile, one round of LDS-atomic ranks is cross-checked against the
                                   ballot-derived ranks (the property rsx_lds_order_kernel tests on an idle device,
                                   here under the real sweeps' LDS contention); a mismatch makes rsx_ctx_check fail */
-    RSX_OPT_SMALL_SORT = 10    /* 1 (default): arrays of at most one tile (14336 4-byte, 7168 8-byte, 2560 16-byte
+    RSX_OPT_SMALL_SORT = 10,   /* 1 (default): arrays of at most one tile (14336 4-byte, 7168 8-byte, 2560 16-byte
                                   elements ...) are sorted by ONE launch of one workgroup; 0: by the general path */
+    RSX_OPT_MID_SORT = 11      /* 1 (default): middle-size arrays (up to 2^22 4-byte, 2^21 8-byte, 2^20 16-byte
+                                  elements) whose most significant digit spreads them over the 256 buckets are split
+                                  by that digit and every bucket is sorted in LDS by one workgroup (two trips through
+                                  memory instead of D); 0: LSD passes always */
 };
 int rsx_ctx_set_option(rsx_ctx *ctx, int option, uint64_t value);
 enum {
@@ -161,6 +165,20 @@ int rsx_histogram_device(rsx_ctx *ctx, const void *d_src, size_t n, const rsx_la
  * receives the 256 uint64 digit counts of the slice. */
 int rsx_partition_device(rsx_ctx *ctx, const void *d_src, void *d_dst, size_t n,
                          const rsx_layout *layout, uint32_t digit, uint64_t *d_hist, void *stream);
+/* The same pass over `nsub` (1..16) independent position sub-ranges of the slice, in two steps, so that a
+ * multi-GPU driver can put the buckets of sub-range 0 on the links while sub-range 1 is still being scattered:
+ * sub-range k = elements [n*k/nsub, n*(k+1)/nsub).
+ *   rsx_partition_count_device    counts `digit` over every sub-range (count phase, mod.rs:90-109, chunk ==
+ *                                 sub-range): d_hist receives nsub x 256 uint64; the context keeps the count
+ *                                 matrices for the scatter calls that follow;
+ *   rsx_partition_scatter_device  stable partition of sub-range k by `digit` (prefix + scatter, mod.rs:110-168):
+ *                                 its elements land in the same position range of d_dst, grouped by digit.
+ * Every scatter call of a count call must name the same src, n, layout, digit and nsub. */
+int rsx_partition_count_device(rsx_ctx *ctx, const void *d_src, size_t n, const rsx_layout *layout, uint32_t digit,
+                               uint32_t nsub, uint64_t *d_hist, void *stream);
+int rsx_partition_scatter_device(rsx_ctx *ctx, const void *d_src, void *d_dst, size_t n, const rsx_layout *layout,
+                                 uint32_t digit, uint32_t nsub, uint32_t k, void *stream);
+
 /* Segmented device copy: for i in [0, nseg): copy len[i] ELEMENTS of
  * `elem_bytes` from d_src + src_off[i] to d_dst + dst_off[i] (offsets in
  * elements).  Places the received (digit, source-GPU) runs after the
@@ -186,6 +204,19 @@ int rsx_bounds_device(rsx_ctx *ctx, const void *d_sorted, size_t n, const rsx_la
 int rsx_bounds_ranges_device(rsx_ctx *ctx, const void *d_data, size_t n, const rsx_layout *layout,
                              const uint64_t *d_queries, const uint64_t *d_ranges, uint32_t nq, uint64_t *d_out,
                              void *stream);
+
+/* One digit of the splitter search with the key prefix kept on the device (no host round trip per digit): for
+ * boundary b (0 .. nb-1), d_ranges[2b], d_ranges[2b+1] name a range of `d_data` sorted by mapped key and
+ * d_prefix[2b], d_prefix[2b+1] hold the low / high 64 bits of the mapped key with the digits above `digit` fixed and
+ * the rest zero.  rsx_splitter_count_device writes d_less[b*256 + j] = elements of range b with key below
+ * prefix_b | j << 8*digit; the caller sums d_less over the ranks (an all-reduce on the device); then
+ * rsx_splitter_pick_device ORs into prefix_b the largest j whose summed count does not exceed d_rank[b].  After digit
+ * 0, rsx_bounds_ranges_device with d_queries = d_prefix gives the final (less, less-or-equal) counts. */
+int rsx_splitter_count_device(rsx_ctx *ctx, const void *d_data, size_t n, const rsx_layout *layout,
+                              const uint64_t *d_ranges, const uint64_t *d_prefix, uint32_t nb, uint32_t digit,
+                              uint64_t *d_less, void *stream);
+int rsx_splitter_pick_device(rsx_ctx *ctx, const uint64_t *d_total, const uint64_t *d_rank, uint64_t *d_prefix,
+                             uint32_t nb, uint32_t digit, void *stream);
 
 /* -- multi-GPU from one process ------------------------------------------- */
 /* Sorts the concatenation slice 0 | slice 1 | ... | slice ndev-1 as ONE array,

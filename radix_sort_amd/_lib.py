@@ -12,7 +12,8 @@ SYMBOLS = [
     "rsx_ctx_create", "rsx_ctx_destroy", "rsx_ctx_reserve", "rsx_ctx_check", "rsx_ctx_set_option", "rsx_ctx_get_info",
     "rsx_ctx_profile", "rsx_ctx_profile_read", "rsx_last_error",
     "rsx_strerror", "rsx_version", "rsx_sort_device", "rsx_sort_host", "rsx_histogram_device",
-    "rsx_partition_device", "rsx_segmented_copy_device", "rsx_bounds_device", "rsx_bounds_ranges_device", "rsx_sort_sharded",
+    "rsx_partition_device", "rsx_partition_count_device", "rsx_partition_scatter_device", "rsx_splitter_count_device",
+    "rsx_splitter_pick_device", "rsx_segmented_copy_device", "rsx_bounds_device", "rsx_bounds_ranges_device", "rsx_sort_sharded",
     "rsx_sort_sharded_ex", "rsx_generate_device", "rsx_verify_device",
 ]
 
@@ -22,7 +23,7 @@ PROF_HIST, PROF_SCAN, PROF_SWEEP, PROF_OTHER, PROF_KINDS = 0, 1, 2, 3, 4
 GEN_UNIFORM, GEN_ZIPF, GEN_STEP, GEN_SORTED, GEN_REVERSED, GEN_CONSTANT, GEN_GEOMETRIC = 0, 1, 2, 3, 4, 5, 6
 GEN_PAYLOAD_ZERO = 0x100
 (OPT_TILE_SCHEDULE, OPT_RANKING, OPT_STATUS_SCOPE, OPT_XCD_MAJOR, OPT_BYTE_COUNTING, OPT_MAX_REGIONS, OPT_HOT_LANES,
- OPT_VERBOSE, OPT_RANK_CHECK, OPT_SMALL_SORT) = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+ OPT_VERBOSE, OPT_RANK_CHECK, OPT_SMALL_SORT, OPT_MID_SORT) = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 INFO_RANK_ATOMIC, INFO_L2_LOCAL, INFO_NUM_CU, INFO_DEVICE, INFO_LAST_PASSES = 1, 2, 3, 4, 5
 SHARD_EXCHANGE_FIRST, SHARD_SORT_FIRST = 0, 1
 
@@ -91,6 +92,10 @@ def load():
     L.rsx_sort_host.argtypes = [vp, vp, sz, lp]
     L.rsx_histogram_device.argtypes = [vp, vp, sz, lp, u32, vp, vp]
     L.rsx_partition_device.argtypes = [vp, vp, vp, sz, lp, u32, vp, vp]
+    L.rsx_partition_count_device.argtypes = [vp, vp, sz, lp, u32, u32, vp, vp]
+    L.rsx_partition_scatter_device.argtypes = [vp, vp, vp, sz, lp, u32, u32, u32, vp]
+    L.rsx_splitter_count_device.argtypes = [vp, vp, sz, lp, vp, vp, u32, u32, vp, vp]
+    L.rsx_splitter_pick_device.argtypes = [vp, vp, vp, vp, u32, u32, vp]
     L.rsx_segmented_copy_device.argtypes = [vp, vp, vp, u32, vp, vp, vp, u32, vp]
     L.rsx_bounds_device.argtypes = [vp, vp, sz, lp, vp, u32, vp, vp]
     L.rsx_bounds_ranges_device.argtypes = [vp, vp, sz, lp, vp, vp, u32, vp, vp]

@@ -176,6 +176,24 @@ class Context:
         lay = d.layout()
         self._check(self._L.rsx_partition_device(self._h, d_src, d_dst, n, ctypes.byref(lay), digit, d_hist, stream))
 
+    def partition_count_device(self, d_src: int, n: int, d: RadixDigits, digit: int, nsub: int, d_hist: int, stream: int = 0):
+        lay = d.layout()
+        self._check(self._L.rsx_partition_count_device(self._h, d_src, n, ctypes.byref(lay), digit, nsub, d_hist, stream))
+
+    def partition_scatter_device(self, d_src: int, d_dst: int, n: int, d: RadixDigits, digit: int, nsub: int, k: int,
+                                 stream: int = 0):
+        lay = d.layout()
+        self._check(self._L.rsx_partition_scatter_device(self._h, d_src, d_dst, n, ctypes.byref(lay), digit, nsub, k, stream))
+
+    def splitter_count_device(self, d_data: int, n: int, d: RadixDigits, d_ranges: int, d_prefix: int, nb: int, digit: int,
+                              d_less: int, stream: int = 0):
+        lay = d.layout()
+        self._check(self._L.rsx_splitter_count_device(self._h, d_data, n, ctypes.byref(lay), d_ranges, d_prefix, nb, digit,
+                                                      d_less, stream))
+
+    def splitter_pick_device(self, d_total: int, d_rank: int, d_prefix: int, nb: int, digit: int, stream: int = 0):
+        self._check(self._L.rsx_splitter_pick_device(self._h, d_total, d_rank, d_prefix, nb, digit, stream))
+
     def segmented_copy_device(self, d_src: int, d_dst: int, elem_bytes: int, d_src_off: int, d_dst_off: int,
                               d_len: int, nseg: int, stream: int = 0):
         self._check(self._L.rsx_segmented_copy_device(self._h, d_src, d_dst, elem_bytes, d_src_off, d_dst_off,

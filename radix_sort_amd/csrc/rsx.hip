@@ -132,6 +132,25 @@ int hist_dispatch(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_
                   unsigned long long* J, unsigned long long* jclear, bool clear_status, hipStream_t st) {
     RSX_DISPATCH_ES(L->elem_bytes, launch_hist, ctx, src, g, L, digit, J, jclear, clear_status, st)
 }
+int hist2_dispatch(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_layout* L, uint32_t digit,
+                   unsigned long long* J, uint32_t digit2, unsigned long long* J2, unsigned long long* jclear, hipStream_t st) {
+    RSX_DISPATCH_ES(L->elem_bytes, launch_hist2, ctx, src, g, L, digit, J, digit2, J2, jclear, st)
+}
+int bucket_dispatch(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L, hipStream_t st) {
+    RSX_DISPATCH_ES(L->elem_bytes, launch_bucket_sort, ctx, src, dst, g, L, st)
+}
+uint64_t mid_max_for(uint32_t es) {
+    switch (es) {
+        case 2: return mid_max_elems(2);
+        case 4: return mid_max_elems(4);
+        case 8: return mid_max_elems(8);
+        case 12: return mid_max_elems(12);
+        case 16: return mid_max_elems(16);
+        case 24: return mid_max_elems(24);
+        case 32: return mid_max_elems(32);
+        default: return 0;
+    }
+}
 int small_dispatch(rsx_ctx* ctx, void* data, size_t n, const rsx_layout* L, hipStream_t st) {
     RSX_DISPATCH_ES(L->elem_bytes, launch_small_sort, ctx, data, n, L, st)
 }
@@ -197,10 +216,16 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
     // at most one tile: all D passes in one launch of one workgroup (rsx_small_kernel.hpp)
     if (!counting_path && n <= (size_t)512 * kpt_for((int)L->elem_bytes) && !(ctx->options & OPT_NO_SMALL_SORT))  // one 512-thread tile
         return small_dispatch(ctx, d_data, n, L, st);
+    // Middle sizes (more than one tile, up to mid_max_elems): the count kernel also counts the MOST significant digit
+    // and the first sweep decides from those counts whether it is the bucket split (then rsx_bucket_sort_kernel
+    // finishes the sort and the sweeps behind it return at once) or the first LSD pass of the general path.
+    const bool mid = !counting_path && D >= 2 && (uint64_t)n <= mid_max_for(L->elem_bytes) && geom.num_regions <= MID_MAX_REGIONS &&
+                     status32(geom) && !(ctx->options & OPT_NO_MID_SORT);
     // count phase of pass 0 (mod.rs:90-109); later passes are counted by the sweep before them
     rc = zero_counters(ctx, geom, st);
     if (rc) return rc;
-    rc = hist_dispatch(ctx, d_data, geom, L, 0, J_of(ctx, 0), D > 1 ? J_of(ctx, 1) : nullptr, !counting_path, st);
+    if (mid) rc = hist2_dispatch(ctx, d_data, geom, L, 0, J_of(ctx, 0), D - 1, JT_of(ctx), J_of(ctx, 1), st);
+    else rc = hist_dispatch(ctx, d_data, geom, L, 0, J_of(ctx, 0), D > 1 ? J_of(ctx, 1) : nullptr, !counting_path, st);
     if (rc) return rc;
     if (counting_path) {
         // u8 / i8: the element is its digit, so the 256 counts ARE the sorted array (same bytes as
@@ -225,9 +250,19 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
         const int xf = (d == 0 ? 1 : 0) | (d + 1 == D ? 2 : 0);  // key map on at the first, off at the last pass
         ctx->pass_index = d;
         ctx->pass_last = d + 1 == D;
+        ctx->pass_mid = mid ? (d == 0 ? 1u : 2u) : 0u;
+        // (middle sizes: the passes behind the first return at once when it made the buckets -- ~4 us per launch all
+        // the same; putting them on a side stream beside the bucket kernel cost more in event hand-offs than it hid:
+        // 2^16 u32 60 -> 75 us)
         rc = sweep_dispatch(ctx, src, dst, geom, L, d, J_of(ctx, d % 3), jnext, jzero, xf, st);  // mod.rs:121-168
+        ctx->pass_mid = 0;
         if (rc) return rc;
+        if (mid && d == 0) {  // the buckets were made in d_tmp; sorted, they land in d_data
+            rc = bucket_dispatch(ctx, d_tmp, d_data, geom, L, st);
+            if (rc) return rc;
+        }
     }
+
     if (D % 2 == 1)  // odd-D copy-back (mod.rs:170-174)
         RSX_HIP(hipMemcpyAsync(d_data, d_tmp, n * (size_t)L->elem_bytes, hipMemcpyDeviceToDevice, st));
     return RSX_OK;
@@ -309,6 +344,7 @@ int rsx_ctx_destroy(rsx_ctx* ctx) try {
             if (s) (void)hipStreamDestroy(s);
         for (hipEvent_t e : ctx->copy_event)
             if (e) (void)hipEventDestroy(e);
+        if (ctx->part_J) (void)hipFree(ctx->part_J);
         if (ctx->shard_q) (void)hipFree(ctx->shard_q);
         if (ctx->shard_out) (void)hipFree(ctx->shard_out);
         if (ctx->shard_hist) (void)hipFree(ctx->shard_hist);
@@ -397,6 +433,10 @@ int rsx_ctx_set_option(rsx_ctx* ctx, int option, uint64_t value) try {
         case RSX_OPT_SMALL_SORT:
             if (value > 1) return fail(ctx, RSX_ERR_ARG, "RSX_OPT_SMALL_SORT: 0 or 1");
             flag(OPT_NO_SMALL_SORT, value == 0);
+            return RSX_OK;
+        case RSX_OPT_MID_SORT:
+            if (value > 1) return fail(ctx, RSX_ERR_ARG, "RSX_OPT_MID_SORT: 0 or 1");
+            flag(OPT_NO_MID_SORT, value == 0);
             return RSX_OK;
         default:
             return fail(ctx, RSX_ERR_ARG, "unknown option");
@@ -693,6 +733,111 @@ int rsx_partition_device(rsx_ctx* ctx, const void* d_src, void* d_dst, size_t n,
     if (!d_src || !d_dst || !aligned(d_src, al) || !aligned(d_dst, al))
         return fail(ctx, RSX_ERR_ARG, "bad device pointer");
     return partition_locked(ctx, d_src, d_dst, n, L, digit, d_hist, st);
+} catch (...) {
+    return RSX_ERR_HIP;
+}
+
+namespace {
+inline uint64_t sub_start(uint64_t n, uint32_t nsub, uint32_t k) { return (uint64_t)(((unsigned __int128)n * k) / nsub); }
+}  // namespace
+
+int rsx_partition_count_device(rsx_ctx* ctx, const void* d_src, size_t n, const rsx_layout* L, uint32_t digit,
+                               uint32_t nsub, uint64_t* d_hist, void* stream) try {
+    int rc = check_common(ctx, L);
+    if (rc) return rc;
+    if (digit >= L->key_bytes) return fail(ctx, RSX_ERR_ARG, "bad digit");
+    if (nsub == 0 || nsub > PART_MAX_SUB || !d_hist) return fail(ctx, RSX_ERR_ARG, "1..16 sub-ranges, non-null histogram");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (n && (!d_src || !aligned(d_src, elem_align(L->elem_bytes)))) return fail(ctx, RSX_ERR_ARG, "bad source pointer");
+    rc = ensure_aux(ctx, st);
+    if (rc) return rc;
+    if (!ctx->part_J) {
+        if (capturing(st)) return fail(ctx, RSX_ERR_WORKSPACE, "sub-range count matrices not allocated before stream capture");
+        RSX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->part_J), (size_t)PART_MAX_SUB * J_BYTES));
+    }
+    Enqueue enq(ctx, st);
+    RSX_HIP(hipMemsetAsync(ctx->part_J, 0, (size_t)nsub * J_BYTES, st));
+    for (uint32_t k = 0; k < nsub; ++k) {
+        const uint64_t beg = sub_start(n, nsub, k), nk = sub_start(n, nsub, k + 1) - beg;
+        if (nk == 0) {
+            RSX_HIP(hipMemsetAsync(d_hist + (size_t)k * RADIX, 0, RADIX * sizeof(uint64_t), st));
+            continue;
+        }
+        const RegionGeom geom = make_geom(ctx, nk, L->elem_bytes);
+        unsigned long long* Jk = ctx->part_J + (size_t)k * (J_BYTES / sizeof(unsigned long long));
+        rc = hist_dispatch(ctx, static_cast<const char*>(d_src) + beg * L->elem_bytes, geom, L, digit, Jk, nullptr, false, st);
+        if (rc) return rc;
+        rc = launch_totals(ctx, geom, Jk, d_hist + (size_t)k * RADIX, st);
+        if (rc) return rc;
+    }
+    return RSX_OK;
+} catch (...) {
+    return RSX_ERR_HIP;
+}
+
+int rsx_partition_scatter_device(rsx_ctx* ctx, const void* d_src, void* d_dst, size_t n, const rsx_layout* L,
+                                 uint32_t digit, uint32_t nsub, uint32_t k, void* stream) try {
+    int rc = check_common(ctx, L);
+    if (rc) return rc;
+    if (digit >= L->key_bytes) return fail(ctx, RSX_ERR_ARG, "bad digit");
+    if (nsub == 0 || nsub > PART_MAX_SUB || k >= nsub) return fail(ctx, RSX_ERR_ARG, "bad sub-range");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint64_t beg = sub_start(n, nsub, k), nk = sub_start(n, nsub, k + 1) - beg;
+    if (nk == 0) return RSX_OK;
+    const uint32_t al = elem_align(L->elem_bytes);
+    if (!d_src || !d_dst || !aligned(d_src, al) || !aligned(d_dst, al)) return fail(ctx, RSX_ERR_ARG, "bad device pointer");
+    if (!ctx->part_J) return fail(ctx, RSX_ERR_ARG, "rsx_partition_count_device has not run on this context");
+    rc = pending_error(ctx);
+    if (rc) return rc;
+    rc = ensure_workspace(ctx, nk, L, st);
+    if (rc) return rc;
+    Enqueue enq(ctx, st);
+    const RegionGeom geom = make_geom(ctx, nk, L->elem_bytes);
+    // what the count kernel of a whole sort clears on its way: this pass's control words and status words
+    RSX_HIP(hipMemsetAsync(tickets_of(ctx, 0), 0, TICKET_WORDS * sizeof(uint32_t), st));
+    RSX_HIP(hipMemsetAsync(ctx->status, 0, status_bytes_for(ctx, nk, L->elem_bytes), st));
+    ctx->pass_index = 0;
+    ctx->pass_last = true;
+    ctx->pass_mid = 0;
+    const size_t off = beg * (size_t)L->elem_bytes;
+    return sweep_dispatch(ctx, static_cast<const char*>(d_src) + off, static_cast<char*>(d_dst) + off, geom, L, digit,
+                          ctx->part_J + (size_t)k * (J_BYTES / sizeof(unsigned long long)), nullptr, nullptr, 3, st);
+} catch (...) {
+    return RSX_ERR_HIP;
+}
+
+int rsx_splitter_count_device(rsx_ctx* ctx, const void* d_data, size_t n, const rsx_layout* L, const uint64_t* d_ranges,
+                              const uint64_t* d_prefix, uint32_t nb, uint32_t digit, uint64_t* d_less, void* stream) try {
+    if (!ctx) return RSX_ERR_ARG;
+    if (!layout_ok(L)) return fail(ctx, RSX_ERR_ARG, "invalid rsx_layout");
+    if (nb == 0) return RSX_OK;
+    if (digit >= L->key_bytes || !d_ranges || !d_prefix || !d_less || (n && !d_data)) return fail(ctx, RSX_ERR_ARG, "bad digit / null pointer");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    hipLaunchKernelGGL(rsx_splitter_count_kernel, dim3(nb), dim3(RADIX), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint8_t*>(d_data), (uint64_t)n, L->elem_bytes, L->key_offset, L->key_bytes, L->key_kind,
+                       d_ranges, d_prefix, digit, d_less);
+    RSX_HIP(hipGetLastError());
+    return RSX_OK;
+} catch (...) {
+    return RSX_ERR_HIP;
+}
+
+int rsx_splitter_pick_device(rsx_ctx* ctx, const uint64_t* d_total, const uint64_t* d_rank, uint64_t* d_prefix, uint32_t nb,
+                             uint32_t digit, void* stream) try {
+    if (!ctx) return RSX_ERR_ARG;
+    if (nb == 0) return RSX_OK;
+    if (digit >= 16 || !d_total || !d_rank || !d_prefix) return fail(ctx, RSX_ERR_ARG, "bad digit / null pointer");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    hipLaunchKernelGGL(rsx_splitter_pick_kernel, dim3(nb), dim3(RADIX), 0, static_cast<hipStream_t>(stream), d_total, d_rank,
+                       d_prefix, digit);
+    RSX_HIP(hipGetLastError());
+    return RSX_OK;
 } catch (...) {
     return RSX_ERR_HIP;
 }

@@ -269,15 +269,18 @@ struct RegionGeom {
 // grid = num_regions * blocks_per_region; a block stays inside one region.
 // (Only the first pass of a sort needs this kernel: each sweep pass counts the
 // next pass's digit per destination region while it scatters.)
-template <int ES, bool FLT>
+// TWO: a second digit (spec2) is counted into a second matrix (J2) on the same read -- the middle-size path
+// counts the least significant digit (its first LSD pass) and the most significant one (its bucket split).
+template <int ES, bool FLT, bool TWO = false>
 __global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restrict__ src, RegionGeom g,
                                                        DigitSpec spec, uint32_t blocks_per_region,
                                                        unsigned long long* __restrict__ J,
                                                        unsigned long long* __restrict__ jclear, uint32_t j32,
-                                                       uint4* __restrict__ zero16, uint64_t zero16_n) {
-    __shared__ uint32_t lh[RADIX];
+                                                       uint4* __restrict__ zero16, uint64_t zero16_n,
+                                                       DigitSpec spec2 = DigitSpec{}, unsigned long long* __restrict__ J2 = nullptr) {
+    __shared__ uint32_t lh[TWO ? 2 * RADIX : RADIX];
     const uint32_t tid = threadIdx.x;
-    if (tid < RADIX) lh[tid] = 0;
+    if (tid < (TWO ? 2 * RADIX : RADIX)) lh[tid] = 0;
     // the count matrix the first sweep accumulates into (the second pass's) is cleared here
     if (jclear != nullptr)
         for (uint32_t i = blockIdx.x * blockDim.x + tid; i < (uint32_t)J_REPL * g.num_regions * RADIX; i += gridDim.x * blockDim.x)
@@ -301,6 +304,7 @@ __global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restric
         } else {
             atomicAdd(&lh[d], 1u);
         }
+        if constexpr (TWO) atomicAdd(&lh[RADIX + elem_digit<ES, FLT>(e, spec2)], 1u);
     };
     // order inside a region does not matter for a count: 16-byte loads
     constexpr int VEC = (ES == 1 || ES == 2 || ES == 4 || ES == 8) ? 16 / ES : 1;
@@ -351,6 +355,13 @@ __global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restric
             if (j32) atomicAdd(reinterpret_cast<uint32_t*>(J) + bin, c);
             else atomicAdd(&J[bin], (unsigned long long)c);
         }
+        if constexpr (TWO) {
+            const uint32_t c2 = lh[RADIX + tid];
+            if (c2) {
+                if (j32) atomicAdd(reinterpret_cast<uint32_t*>(J2) + bin, c2);
+                else atomicAdd(&J2[bin], (unsigned long long)c2);
+            }
+        }
     }
 }
 
@@ -396,6 +407,13 @@ struct SweepArgs {
     DigitSpec next;               // next pass's digit (when jnext != null)
     KeyXform xf;                  // signed/float key map applied on load (XF & 1) / undone on store (XF & 2)
     uint32_t opts;                // alternative paths, all bit-exact: SWEEP_OPT_*
+    // middle-size path (MID instantiation: the sort's first sweep): this launch is EITHER the bucket split by the
+    // most significant digit (then rsx_bucket_sort_kernel finishes the sort) OR the first LSD pass, decided here
+    // from the top digit's counts; `mid_flag` tells the kernels behind which (1 = buckets, 2 = LSD)
+    const unsigned long long* mid_J;  // count matrix of the most significant digit
+    DigitSpec mid_spec;           // the most significant digit (of the mapped key)
+    uint32_t mid_cap;             // largest bucket rsx_bucket_sort_kernel takes
+    uint32_t* mid_flag;           // MID: written; other sweeps of the sort: read (1 = nothing left to do), or null
     uint32_t dbg;                 // RSX_TUNING builds: timing-only ablation switches (0 in production)
     unsigned long long* dbg_cnt;  // [8] diagnostic counters (RSX_TUNING, dbg & 0x100)
 };
@@ -564,7 +582,7 @@ __device__ __forceinline__ void load_tile(Elem<ES> (&e)[KPT], const Elem<ES>* __
     }
 }
 
-template <int ES, int KPT, int WG, typename S, int XF, bool NEXT>
+template <int ES, int KPT, int WG, typename S, int XF, bool NEXT, bool MID = false>
 // VGPR budget: 4-byte (and narrower) keys carry 16 elements per thread and need ~104 VGPRs; capping
 // them at 80 (3 workgroups/CU) spills, and the spills cost more than the third workgroup buys
 // (measured: 0.82 -> 0.68 ms per 256M-key pass at 2 workgroups/CU without spills).
@@ -596,6 +614,12 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
     uint32_t* s_misc = s_jn + (NEXT ? a.g.num_regions * RADIX : 0);                    // [32]
     static_assert(NWAVE * RADIX * sizeof(Cnt) >= RADIX * sizeof(uint64_t), "s_base must fit in s_whist");
 
+    if constexpr (!MID) {
+        // middle-size sorts: the first sweep decided that rsx_bucket_sort_kernel finishes the sort -- nothing to do here
+        if (a.mid_flag != nullptr &&
+            __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.mid_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 1)
+            return;
+    }
     const E* __restrict__ src = static_cast<const E*>(a.src);
     S* status = static_cast<S*>(a.status);
     const uint32_t NR = a.g.num_regions;
@@ -659,7 +683,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
     uint64_t* s_scan = reinterpret_cast<uint64_t*>(s_misc + 16);  // [4]
     uint64_t* s_half = reinterpret_cast<uint64_t*>(s_elems);       // [2][256]: the tile area is free between tiles
     static_assert(TILE_BYTES >= 2 * RADIX * sizeof(uint64_t), "scratch of the prefix phase lives in the tile area");
-    auto load_counts = [&](uint32_t r, uint64_t& tot, uint64_t& below) {  // partial column sums of thread t
+    auto load_counts = [&](const unsigned long long* Jm, uint32_t r, uint64_t& tot, uint64_t& below) {  // partial column sums of thread t
         tot = 0;
         below = 0;
         constexpr uint32_t HALVES = WG >= 2 * RADIX ? 2 : 1;
@@ -667,7 +691,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         uint32_t t = threadIdx.x;
         asm volatile("" : "+v"(t));  // opaque: the column address is not worth a register pair across the tile loop
         if (t < HALVES * RADIX) {
-            const JT* col = reinterpret_cast<const JT*>(a.J) + (size_t)(t >> 8) * RPH * NR * RADIX + (t & 255u);
+            const JT* col = reinterpret_cast<const JT*>(Jm) + (size_t)(t >> 8) * RPH * NR * RADIX + (t & 255u);
             constexpr uint32_t QU = ES >= 16 ? 4 : 8;  // loads in flight: RPH * QU (the 16-byte kernels run at 80 VGPRs)
             for (uint32_t q0 = 0; q0 < NR; q0 += QU) {
 #pragma unroll
@@ -711,13 +735,50 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         }
         __syncthreads();
     };
+    // MID: which digit this launch partitions by, and from which count matrix, is decided below
+    DigitSpec spec = a.spec;
+    const unsigned long long* Jsel = a.J;
+    bool msd = false;
     auto region_cursors = [&](uint32_t r) {  // r is wave-uniform
         uint64_t tot, below;
-        load_counts(r, tot, below);
+        load_counts(Jsel, r, tot, below);
         scan_cursors(tot, below);
     };
     uint64_t tot_home, below_home;
-    load_counts(home, tot_home, below_home);
+    if constexpr (MID) {
+        // Middle-size sort, first sweep.  If no bucket of the MOST significant digit exceeds what one workgroup sorts
+        // in LDS (a.mid_cap), this launch splits the array into those 256 buckets and rsx_bucket_sort_kernel sorts
+        // each by the remaining digits (two trips through memory instead of D); else it is the ordinary first LSD
+        // pass.  Every workgroup takes the same decision from the same counts; workgroup 0 records it.
+        load_counts(a.mid_J, home, tot_home, below_home);
+        const uint32_t t = threadIdx.x;
+        if (WG >= 2 * RADIX && t >= RADIX && t < 2 * RADIX) s_half[t - RADIX] = tot_home;
+        __syncthreads();
+        uint64_t c = 0;
+        if (t < RADIX) c = tot_home + (WG >= 2 * RADIX ? s_half[t] : 0ull);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint64_t y = __shfl_xor(c, o);
+            c = y > c ? y : c;
+        }
+        if (t < RADIX && (t & 63u) == 0u) s_scan[t >> 6] = c;
+        __syncthreads();
+        uint64_t big = s_scan[0];
+#pragma unroll
+        for (int w = 1; w < RADIX / WAVE; ++w) big = s_scan[w] > big ? s_scan[w] : big;
+        msd = __builtin_amdgcn_readfirstlane((int)(big <= (uint64_t)a.mid_cap)) != 0;
+        __syncthreads();  // s_half / s_scan are used again by scan_cursors
+        if (msd) {
+            spec = a.mid_spec;
+            Jsel = a.mid_J;
+        } else {
+            load_counts(a.J, home, tot_home, below_home);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) *a.mid_flag = msd ? 1u : 2u;
+    } else {
+        load_counts(a.J, home, tot_home, below_home);
+    }
+    const bool do_next = NEXT && !(MID && msd);  // the bucket split has no next pass to count for
 #ifdef RSX_STAMPS
     const unsigned long long stamp_entry = __builtin_amdgcn_s_memtime();
 #endif
@@ -932,7 +993,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                 for (int r = 0; r < RG; ++r) {
                     const int j = j0 + r;
                     if (j >= JE) continue;
-                    uint32_t d = elem_digit<ES, false>(e[j], a.spec);
+                    uint32_t d = elem_digit<ES, false>(e[j], spec);
                     if constexpr (!FULL) {
                         if (seg + j * WAVE >= valid) d = 255u;
                     }
@@ -1005,7 +1066,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                 for (int r = 0; r < RG; ++r) {
                     const int j = j0 + r;
                     if (j >= KPT) continue;
-                    uint32_t d = elem_digit<ES, false>(e[j], a.spec);
+                    uint32_t d = elem_digit<ES, false>(e[j], spec);
                     if constexpr (!FULL) {
                         if (seg + j * WAVE >= valid) d = 255u;
                     }
@@ -1158,7 +1219,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         forget<ES, KPT>(e);
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
-            const uint32_t d = (!full && seg + j * WAVE >= valid) ? 255u : elem_digit<ES, false>(e[j], a.spec);
+            const uint32_t d = (!full && seg + j * WAVE >= valid) ? 255u : elem_digit<ES, false>(e[j], spec);
             // bank swizzle (RSX_LDS_SWIZZLE): slot p lives at p ^ ((p >> 5) & 31).  Digit runs that start
             // a multiple of 32 slots apart -- every pass over already sorted input, key = index -- would
             // otherwise put all 64 lanes of a wave on one bank
@@ -1269,7 +1330,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                         E x;
                         if (i < PREREAD && preread) x = e[i];
                         else x = s_elems[slot_of(i)];
-                        const uint64_t idx = s_base[elem_digit<ES, false>(x, a.spec)] + p;
+                        const uint64_t idx = s_base[elem_digit<ES, false>(x, spec)] + p;
                         if constexpr ((XF & 2) != 0) {  // last pass: back to the caller's representation
                             E y = x;
                             key_map<ES, true>(y, a.xf);
@@ -1278,6 +1339,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                             dst[idx] = x;
                         }
                         if constexpr (NEXT) {
+                          if (!MID || do_next) {
                             if constexpr (CROWD) {
                                 const uint32_t bin = next_bin(idx, x);
                                 uint64_t same = __ballot(bin == hot_bin);
@@ -1296,6 +1358,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                             } else if (!RSX_DBG(a, 0x8u)) {
                                 atomicAdd(&s_jn[next_bin(idx, x)], 1u);  // (0x8: ablation, no next-pass count)
                             }
+                          }
                         }
                         // (element by element on purpose: issuing a group's LDS reads ahead of its atomics was
                         // measured no faster on u32 and slower on 8/16-byte elements)
@@ -1308,7 +1371,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                 // check, wave match on crowded bins); else one plain atomic per element.
                 bool crowded_next = false;
                 uint32_t hot_nd = 0;
-                if (NEXT) {
+                if (do_next) {
                     const uint32_t nd = elem_digit<ES, false>(s_elems[sw0], a.next);
                     hot_nd = (uint32_t)__builtin_amdgcn_readfirstlane((int)nd);
                     crowded_next = __popcll(__ballot(nd == hot_nd)) >= 16;
@@ -1321,7 +1384,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                     const uint32_t p = i * WG + tid;
                     if (p < valid) {
                         const E x = s_elems[slot_of(i)];
-                        const uint64_t idx = s_base[elem_digit<ES, false>(x, a.spec)] + p;
+                        const uint64_t idx = s_base[elem_digit<ES, false>(x, spec)] + p;
                         if constexpr ((XF & 2) != 0) {
                             E y = x;
                             key_map<ES, true>(y, a.xf);
@@ -1329,7 +1392,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                         } else {
                             dst[idx] = x;
                         }
-                        if (NEXT)
+                        if (do_next)
                             count_next(s_jn, next_bin(idx, x));
                     }
                 }
@@ -1339,7 +1402,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         RSX_STAMP(6);
     }
 
-    if (NEXT) {  // hand this workgroup's share of the next count matrix over
+    if (do_next) {  // hand this workgroup's share of the next count matrix over
         for (uint32_t i = threadIdx.x; i < a.g.num_regions * RADIX; i += WG) {
             const uint32_t c = s_jn[i];
             if (c)

@@ -9,6 +9,9 @@
 namespace rsxh {
 template int launch_hist<RSX_ES>(rsx_ctx*, const void*, const RegionGeom&, const rsx_layout*, uint32_t,
                                  unsigned long long*, unsigned long long*, bool, hipStream_t);
+template int launch_hist2<RSX_ES>(rsx_ctx*, const void*, const RegionGeom&, const rsx_layout*, uint32_t, unsigned long long*,
+                                  uint32_t, unsigned long long*, unsigned long long*, hipStream_t);
+template int launch_bucket_sort<RSX_ES>(rsx_ctx*, const void*, void*, const RegionGeom&, const rsx_layout*, hipStream_t);
 template int launch_sweep<RSX_ES>(rsx_ctx*, const void*, void*, const RegionGeom&, const rsx_layout*, uint32_t,
                                   const unsigned long long*, unsigned long long*, unsigned long long*, int, hipStream_t);
 template int launch_small_sort<RSX_ES>(rsx_ctx*, void*, size_t, const rsx_layout*, hipStream_t);

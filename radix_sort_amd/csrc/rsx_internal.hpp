@@ -31,7 +31,16 @@ constexpr int MAX_PASSES = 16;                                                  
 constexpr size_t J_BYTES = (size_t)J_REPL * MAX_REGIONS * RADIX * sizeof(uint64_t);  // one count matrix, all replicas
 constexpr size_t TICKET_WORDS = ROLL_SHARDS + (size_t)ROLL_SHARD_COUNT * ROLL_SHARD_STRIDE;  // per pass (rsx_device.hpp)
 constexpr size_t OFF_TICKETS = 0;                                                // [MAX_PASSES][TICKET_WORDS] u32
-constexpr size_t OFF_J0 = ((MAX_PASSES * TICKET_WORDS * 4 + 255) / 256) * 256;
+// middle-size sorts: count matrix of the MOST significant digit (at most MID_MAX_REGIONS regions), between the control
+// words and count matrix 0 so that the one memset of a sort clears it too
+constexpr uint32_t PART_MAX_SUB = 16;  // sub-ranges of rsx_partition_count_device / rsx_partition_scatter_device
+constexpr uint32_t MID_MAX_REGIONS = 8;
+constexpr size_t OFF_JT = ((MAX_PASSES * TICKET_WORDS * 4 + 255) / 256) * 256;
+constexpr size_t JT_BYTES = (size_t)J_REPL * MID_MAX_REGIONS * RADIX * sizeof(uint64_t);
+constexpr size_t OFF_J0 = OFF_JT + JT_BYTES;
+// word of pass 0's control block that tells the kernels behind the first sweep of a middle-size sort what it decided
+constexpr uint32_t MID_FLAG_WORD = MAX_REGIONS + 2;
+static_assert(MID_FLAG_WORD < (uint32_t)ROLL_SHARDS, "control words of a pass");
 constexpr size_t OFF_J1 = OFF_J0 + J_BYTES;
 constexpr size_t OFF_J2 = OFF_J1 + J_BYTES;
 constexpr size_t OFF_BASE = OFF_J2 + J_BYTES;                                    // scratch of the context self-tests
@@ -50,6 +59,7 @@ enum : uint32_t {
     OPT_VERBOSE = 1u << 6,
     OPT_RANK_CHECK = 1u << 7,      // cross-check atomic ranks against ballots on real tiles (tests)
     OPT_NO_SMALL_SORT = 1u << 8,   // arrays of at most one tile through the general path too
+    OPT_NO_MID_SORT = 1u << 9,     // middle sizes through the general path too (no bucket split)
 };
 
 }  // namespace rsxh
@@ -70,6 +80,7 @@ struct rsx_ctx {
     void* pinned[4] = {nullptr, nullptr, nullptr, nullptr};  // ring of pinned bounce chunks
     hipEvent_t copy_event[4] = {nullptr, nullptr, nullptr, nullptr};
     // multi-GPU driver (rsx_sort_sharded): per-slice stream and splitter-search scratch, made once
+    unsigned long long* part_J = nullptr;  // rsx_partition_count_device: one count matrix per sub-range (PART_MAX_SUB x J_BYTES)
     hipStream_t shard_stream = nullptr;
     uint64_t* shard_q = nullptr;     // device: queries (lo, hi) + ranges (begin, end)
     uint64_t* shard_out = nullptr;   // device: answers
@@ -80,6 +91,7 @@ struct rsx_ctx {
     uint32_t pass_index = 0;   // of the sweep being launched within its sort (selects the status half, J rotation)
     bool pass_last = true;     // no pass follows: nothing to clean
     uint32_t last_sort_passes = 0;  // sweep passes of the last sort (RSX_INFO_LAST_PASSES)
+    uint32_t pass_mid = 0;     // middle-size sort: 1 = the sweep being launched decides (MID instantiation), 2 = it reads the decision
     bool rank_atomic = false;  // LDS atomic ordering self-test passed (set when the workspace is first made)
     bool l2_local = false;     // same-XCD hand-off self-test passed: chains may keep status words in their L2
     uint32_t hot_lanes = 16;
@@ -148,6 +160,9 @@ struct LaunchTimer {
 // still fit a CU: u32 28 x 512 = 14336 keys (56 KiB), u64 14 x 512 (56 KiB), 16-byte 5 x 512 (40 KiB),
 // 12-byte 10 x 512 (60 KiB), 24-byte 5 x 512 (60 KiB), 32-byte 3 x 512 (48 KiB).
 // Measured against 16 / 8 / 4: 1B u32 117 -> 136, 1B u64 32 -> 34.9, 128M (u64,u64) 17.3 -> 18 Gkeys/s.
+#ifndef RSX_REGION_FLOOR
+#define RSX_REGION_FLOOR 6  // log2 of the fewest tiles worth a region of their own
+#endif
 #ifndef RSX_KPT4
 #define RSX_KPT4 28
 #endif
@@ -175,6 +190,13 @@ struct LaunchTimer {
 #ifndef RSX_WG8
 #define RSX_WG8 512
 #endif
+// rsx_bucket_sort_kernel: 1024 threads x BKPT elements in registers, the bucket in LDS (<= 112 KiB) beside 16 KiB of
+// wave counters
+constexpr int bucket_kpt_for(int es) { return es <= 4 ? 28 : es == 8 ? 14 : es == 12 ? 9 : es == 16 ? 7 : es == 24 ? 4 : 3; }
+constexpr uint32_t bucket_cap(int es) { return 1024u * (uint32_t)bucket_kpt_for(es); }
+// Largest array taken by the middle-size path: the average bucket is 4/7 of the capacity, so uniform top digits
+// pass with a wide margin (2^22 4-byte, 2^21 8-byte, 2^20 16-byte elements); skewed ones fall back to LSD passes.
+constexpr uint64_t mid_max_elems(int es) { return (uint64_t)bucket_cap(es) * 256u * 4u / 7u; }
 constexpr int kpt_for(int es) { return es <= 2 ? RSX_KPT2 : es <= 4 ? RSX_KPT4 : es == 8 ? RSX_KPT8 : es == 12 ? RSX_KPT12 : es == 16 ? RSX_KPT16 : es == 24 ? RSX_KPT24 : RSX_KPT32; }
 constexpr int wg_for(int es) { return es <= 4 ? RSX_WG4 : es == 8 ? RSX_WG8 : 512; }
 constexpr uint32_t tile_elems(int es) { return wg_for(es) * kpt_for(es); }
@@ -191,7 +213,7 @@ inline RegionGeom make_geom(const rsx_ctx* ctx, uint64_t n, uint32_t es) {
     // own, and widens every workgroup's count-matrix flush.  Measured with one region per 2^k keys: 2^18 u32
     // 109 -> 87 us, 2^22 u32 148 -> 134 us, 2^18 u64 249 -> 166 us, 2^22 u64 360 -> 275 us; large inputs are
     // bounded by `cap` as before.
-    k += 6;
+    k += RSX_REGION_FLOOR;
     // the next pass's count matrix costs 1 KiB of LDS per region: 8 where the tile needs the room
     const uint64_t cap = ctx->max_regions ? ctx->max_regions : (es == 8 || es == 32) ? 16 : 8;
     while (((n + (1ull << k) - 1) >> k) > cap) ++k;
@@ -236,6 +258,8 @@ inline unsigned long long* J_of(rsx_ctx* c, uint32_t which) {
     const size_t off = which == 0 ? OFF_J0 : which == 1 ? OFF_J1 : OFF_J2;
     return reinterpret_cast<unsigned long long*>(c->aux + off);
 }
+inline unsigned long long* JT_of(rsx_ctx* c) { return reinterpret_cast<unsigned long long*>(c->aux + OFF_JT); }
+inline uint32_t* mid_flag_of(rsx_ctx* c) { return reinterpret_cast<uint32_t*>(c->aux + OFF_TICKETS) + MID_FLAG_WORD; }
 inline uint64_t* base_of(rsx_ctx* c) { return reinterpret_cast<uint64_t*>(c->aux + OFF_BASE); }
 inline uint32_t* tickets_of(rsx_ctx* c, uint32_t pass) {
     return reinterpret_cast<uint32_t*>(c->aux + OFF_TICKETS) + (size_t)pass * TICKET_WORDS;
@@ -249,6 +273,13 @@ inline uint32_t* flags_of(rsx_ctx* c) { return reinterpret_cast<uint32_t*>(c->au
 template <int ES>
 int launch_hist(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_layout* L, uint32_t digit,
                 unsigned long long* J, unsigned long long* jclear, bool clear_status, hipStream_t st);
+// the same counting a second digit (`digit2` into `J2`) on the same read (middle-size path)
+template <int ES>
+int launch_hist2(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_layout* L, uint32_t digit,
+                 unsigned long long* J, uint32_t digit2, unsigned long long* J2, unsigned long long* jclear, hipStream_t st);
+// second half of a middle-size sort: the 256 top-digit buckets of `src` sorted by the lower digits into `dst`
+template <int ES>
+int launch_bucket_sort(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L, hipStream_t st);
 // one sweep pass.  J: this pass's count matrix; jnext: accumulated for the next pass (or null);
 // jzero: matrix to clear for the pass after next (or null); xf: bit 0 = map signed/float keys on
 // load (first pass), bit 1 = map back on store (last pass)

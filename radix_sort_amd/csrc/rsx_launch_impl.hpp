@@ -36,6 +36,29 @@ int launch_hist(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_la
     return launch_hist_t<ES, false>(ctx, src, g, L, digit, J, jclear, clear_status, st);
 }
 
+template <int ES>
+int launch_hist2(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_layout* L, uint32_t digit,
+                 unsigned long long* J, uint32_t digit2, unsigned long long* J2, unsigned long long* jclear, hipStream_t st) {
+    const uint64_t per_block = 512ull * 16;
+    const uint64_t zero16_n = status_rows(g, ES) * RADIX * (status32(g) ? 4u : 8u) / 16u;
+    uint64_t bpr = ((1ull << g.region_shift) + per_block - 1) / per_block;
+    const uint64_t cap = ((uint64_t)ctx->num_cu * RSX_HIST_BLOCKS_PER_CU + g.num_regions - 1) / g.num_regions;
+    if (bpr > cap) bpr = cap;
+    if (bpr == 0) bpr = 1;
+    LaunchTimer lt(ctx, RSX_PROF_HIST, st);
+    // one instantiation per key kind class: the general digit map is the identity for unsigned keys' specs
+    if (L->key_kind != RSX_KEY_UNSIGNED)
+        hipLaunchKernelGGL((rsx_hist_kernel<ES, true, true>), dim3((uint32_t)(bpr * g.num_regions)), dim3(512), 0, st,
+                           static_cast<const Elem<ES>*>(src), g, make_spec(L, digit), (uint32_t)bpr, J, jclear, status32(g) ? 1u : 0u,
+                           static_cast<uint4*>(ctx->status), zero16_n, make_spec(L, digit2), J2);
+    else
+        hipLaunchKernelGGL((rsx_hist_kernel<ES, false, true>), dim3((uint32_t)(bpr * g.num_regions)), dim3(512), 0, st,
+                           static_cast<const Elem<ES>*>(src), g, make_spec(L, digit), (uint32_t)bpr, J, jclear, status32(g) ? 1u : 0u,
+                           static_cast<uint4*>(ctx->status), zero16_n, make_spec(L, digit2), J2);
+    RSX_HIP(hipGetLastError());
+    return RSX_OK;
+}
+
 // ---- scatter phase: one sweep pass -------------------------------------------------------------
 // the per-dword masks of the signed/float key map (KeyXform in rsx_device.hpp)
 inline KeyXform make_xform(const rsx_layout* L) {
@@ -57,7 +80,7 @@ inline KeyXform make_xform(const rsx_layout* L) {
     return x;
 }
 
-template <int ES, typename S, int XF, bool NEXT>
+template <int ES, typename S, int XF, bool NEXT, bool MID = false>
 int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L,
                    uint32_t digit, const unsigned long long* J, unsigned long long* jnext, unsigned long long* jzero,
                    hipStream_t st) {
@@ -93,12 +116,22 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
              ((ctx->options & OPT_RANK_CHECK) ? SWEEP_OPT_RANK_CHECK : 0u) |
              ((uint64_t)g.n * ES <= (2ull << 30) ? SWEEP_OPT_PREREAD : 0u);  // measured: a gain up to 2 GiB of data, a loss at 4 GiB
     a.dbg = ctx->dbg;
+    a.mid_J = nullptr;
+    a.mid_spec = a.spec;
+    a.mid_cap = 0;
+    a.mid_flag = ctx->pass_mid ? mid_flag_of(ctx) : nullptr;
+    if constexpr (MID) {
+        a.mid_J = JT_of(ctx);
+        a.mid_spec = make_spec(L, L->key_bytes - 1);
+        a.mid_spec.flip = 0;
+        a.mid_cap = bucket_cap(ES);
+    }
     a.rank_atomic = (ctx->rank_atomic && !(ctx->options & OPT_BALLOT_RANKS)) ? 1u : 0u;
     a.hot_lanes = (ctx->options & OPT_ATOMIC_RANKS) ? 65u : ctx->hot_lanes;
     a.dbg_cnt = reinterpret_cast<unsigned long long*>(ctx->aux + OFF_DBG);
     const size_t lds = (size_t)TILE * ES + (SWEEP_WG / WAVE) * RADIX * ((RSX_WIDE_CNT && ES <= 4 && KPT >= 16 && SWEEP_WG <= 512) ? sizeof(uint32_t) : sizeof(uint16_t)) +
                        (NEXT ? (size_t)g.num_regions * RADIX * sizeof(uint32_t) : 0) + 128;
-    auto kern = rsx_sweep_kernel<ES, KPT, SWEEP_WG, S, XF, NEXT>;
+    auto kern = rsx_sweep_kernel<ES, KPT, SWEEP_WG, S, XF, NEXT, MID>;
     // resident workgroups per CU for this kernel at this LDS size (the count matrix of the next pass
     // makes the LDS size depend on the number of regions): cached per instantiation and thread
     thread_local size_t occ_lds = ~(size_t)0;
@@ -166,6 +199,9 @@ int launch_sweep_n(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
                    uint32_t digit, const unsigned long long* J, unsigned long long* jnext, unsigned long long* jzero,
                    hipStream_t st) {
     if constexpr ((XF & 2) == 0) {  // a pass that maps the keys back is a last pass: nothing to count for
+        if constexpr (sizeof(S) == 4 && ES != 1) {  // the first sweep of a middle-size sort (regions of <= 2^30 elements by far)
+            if (jnext && ctx->pass_mid == 1) return launch_sweep_t<ES, S, XF, true, true>(ctx, src, dst, g, L, digit, J, jnext, jzero, st);
+        }
         if (jnext) return launch_sweep_t<ES, S, XF, true>(ctx, src, dst, g, L, digit, J, jnext, jzero, st);
     } else if (jnext) {
         return fail(ctx, RSX_ERR_ARG, "a last pass cannot count for a next one");
@@ -200,11 +236,12 @@ int launch_small_sort(rsx_ctx* ctx, void* data, size_t n, const rsx_layout* L, h
     if (n == 0 || n > (size_t)512 * KPT || L->key_bytes > 16) return fail(ctx, RSX_ERR_INTERNAL, "launch_small_sort: size out of range");
     SmallArgs a;
     std::memset(&a, 0, sizeof a);
+    a.src = data;
     a.data = data;
     a.n = (uint32_t)n;
     a.passes = L->key_bytes;
     a.rank_atomic = (ctx->rank_atomic && !(ctx->options & OPT_BALLOT_RANKS)) ? 1u : 0u;
-    a.map_keys = L->key_kind == RSX_KEY_UNSIGNED ? 0u : 1u;
+    a.map_load = a.map_store = L->key_kind == RSX_KEY_UNSIGNED ? 0u : 1u;
     for (uint32_t d = 0; d < L->key_bytes; ++d) {
         a.spec[d] = make_spec(L, d);
         a.spec[d].flip = 0;  // the kernel sees mapped keys: plain digits
@@ -216,6 +253,46 @@ int launch_small_sort(rsx_ctx* ctx, void* data, size_t n, const rsx_layout* L, h
     hipLaunchKernelGGL(kern, dim3(1), dim3(512), lds, st, a);
     RSX_HIP(hipGetLastError());
     return RSX_OK;
+}
+
+// ---- middle-size sorts: the 256 top-digit buckets, each sorted by one workgroup ------------------
+template <int ES>
+int launch_bucket_sort(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L, hipStream_t st) {
+    if constexpr (ES == 1) {
+        return fail(ctx, RSX_ERR_INTERNAL, "launch_bucket_sort: one-byte elements");
+    } else {
+        constexpr int KPT = bucket_kpt_for(ES);
+        if (L->key_bytes < 2 || L->key_bytes > 16) return fail(ctx, RSX_ERR_INTERNAL, "launch_bucket_sort: key width out of range");
+        SmallArgs a;
+        std::memset(&a, 0, sizeof a);
+        a.src = src;
+        a.data = dst;
+        a.passes = L->key_bytes - 1;
+        a.rank_atomic = (ctx->rank_atomic && !(ctx->options & OPT_BALLOT_RANKS)) ? 1u : 0u;
+        a.map_load = 0;  // the first sweep mapped the keys
+        a.map_store = L->key_kind == RSX_KEY_UNSIGNED ? 0u : 1u;
+        for (uint32_t d = 0; d + 1 < L->key_bytes; ++d) {
+            a.spec[d] = make_spec(L, d);
+            a.spec[d].flip = 0;
+        }
+        a.xf = make_xform(L);
+        a.top_J = JT_of(ctx);
+        a.num_regions = g.num_regions;
+        a.j32 = status32(g) ? 1u : 0u;
+        a.mid_flag = mid_flag_of(ctx);
+        a.error = ctx->host_err_dev;
+        const size_t lds = (size_t)1024 * KPT * ES + 16 * RADIX * sizeof(uint32_t) + 64;
+        auto kern = rsx_bucket_sort_kernel<ES, KPT>;
+        static thread_local bool attr_set = false;
+        if (!attr_set) {  // more than 64 KiB of dynamic LDS has to be asked for
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        LaunchTimer lt(ctx, RSX_PROF_OTHER, st);
+        hipLaunchKernelGGL(kern, dim3(RADIX), dim3(1024), lds, st, a);
+        RSX_HIP(hipGetLastError());
+        return RSX_OK;
+    }
 }
 
 template <int ES>

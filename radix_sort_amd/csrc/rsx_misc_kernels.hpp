@@ -370,6 +370,56 @@ __global__ __launch_bounds__(256) void rsx_bounds_kernel(const uint8_t* __restri
     out[nq + qi] = lo - (begin < end ? begin : end);
 }
 
+// ---- splitter search, one digit per launch, no host in the loop ----------------------------------
+// The multi-GPU schedules cut sorted ranges at exact global ranks: digit by digit from the top, 256 candidate keys
+// per boundary are counted in every rank's range, the counts are summed over the ranks (an all-reduce) and the
+// largest candidate whose global count does not exceed the boundary's rank fixes the digit.  These two kernels keep
+// the key prefix on the device, so that the digits follow each other stream-ordered: count -> all-reduce -> pick.
+//
+// less[b * 256 + j] = elements of range b, [ranges[2b], ranges[2b+1]) of `data` (sorted by mapped key), whose key is
+// below prefix[b] | j << 8*digit.  prefix[2b], prefix[2b+1] = low / high 64 bits of the mapped-key prefix.
+// grid = boundaries, block = 256 (one candidate per thread).
+__global__ __launch_bounds__(256) void rsx_splitter_count_kernel(const uint8_t* __restrict__ data, uint64_t n, uint32_t elem_bytes,
+                                                                 uint32_t key_offset, uint32_t key_bytes, uint32_t kind,
+                                                                 const uint64_t* __restrict__ ranges,
+                                                                 const uint64_t* __restrict__ prefix, uint32_t digit,
+                                                                 uint64_t* __restrict__ less) {
+    const uint32_t b = blockIdx.x, j = threadIdx.x;
+    uint64_t qlo = prefix[2 * b], qhi = prefix[2 * b + 1];
+    if (digit < 8) qlo |= (uint64_t)j << (8 * digit);
+    else qhi |= (uint64_t)j << (8 * (digit - 8));
+    const uint64_t begin = ranges[2 * b];
+    uint64_t end = ranges[2 * b + 1];
+    if (end > n) end = n;
+    uint64_t lo = begin < end ? begin : end, hi = end;
+    const uint64_t base = lo;
+    while (lo < hi) {  // first element with key >= Q
+        const uint64_t mid = lo + (hi - lo) / 2;
+        uint64_t klo, khi;
+        mapped_key(data + mid * elem_bytes, key_offset, key_bytes, kind, klo, khi);
+        if (khi < qhi || (khi == qhi && klo < qlo)) lo = mid + 1;
+        else hi = mid;
+    }
+    less[(size_t)b * RADIX + j] = lo - base;
+}
+
+// prefix[b] |= pick << 8*digit with pick = the largest j whose summed count total[b * 256 + j] does not exceed rank[b]
+// (the counts are monotone in j and total[b * 256] <= rank[b] always: it counts keys below the prefix itself)
+__global__ __launch_bounds__(256) void rsx_splitter_pick_kernel(const uint64_t* __restrict__ total, const uint64_t* __restrict__ rank,
+                                                                uint64_t* __restrict__ prefix, uint32_t digit) {
+    __shared__ uint32_t cnt[4];
+    const uint32_t b = blockIdx.x, j = threadIdx.x;
+    const uint64_t ok = __ballot(total[(size_t)b * RADIX + j] <= rank[b]);
+    if ((j & 63u) == 0u) cnt[j >> 6] = (uint32_t)__popcll(ok);
+    __syncthreads();
+    if (j == 0) {
+        const uint32_t below = cnt[0] + cnt[1] + cnt[2] + cnt[3];  // candidates 0 .. below-1 qualify
+        const uint64_t pick = below ? below - 1u : 0u;
+        if (digit < 8) prefix[2 * b] |= pick << (8 * digit);
+        else prefix[2 * b + 1] |= pick << (8 * (digit - 8));
+    }
+}
+
 __global__ __launch_bounds__(256) void rsx_verify_kernel(const uint8_t* __restrict__ data, uint64_t n,
                                                          uint32_t elem_bytes, uint32_t key_offset, uint32_t key_bytes,
                                                          uint32_t kind, uint64_t* __restrict__ out) {

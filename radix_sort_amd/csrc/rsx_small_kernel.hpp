@@ -1,40 +1,55 @@
-// rsx_small_kernel.hpp -- arrays of at most one tile: the whole sort in ONE launch of ONE workgroup.
+// rsx_small_kernel.hpp -- sorts that ONE workgroup finishes in LDS.
 //
-// The general path costs a memset, a count kernel and D sweeps whatever the size (>= 4.5 us each, and a
-// sweep of one tile still walks its roll call, cursors and flush): 70 us for 1000 u32 keys.  Here the
-// elements live in registers and LDS for all D passes of mod.rs:84-169: per pass, stable ranks inside each
+//  rsx_small_sort_kernel   arrays of at most one tile: the whole sort in ONE launch of ONE workgroup.
+//  rsx_bucket_sort_kernel  the second half of a middle-size sort: the first sweep has split the array into the 256
+//                          buckets of its MOST significant digit (a stable partition: bucket v sits at its final
+//                          position range, in input order); workgroup v sorts bucket v by the remaining D-1
+//                          digits.  Two trips through memory instead of D, and one launch instead of D-1.
+//
+// The general path costs a memset, a count kernel and D sweeps whatever the size (>= 10 us each: a sweep of one
+// tile still walks its roll call, cursors and flush): 70 us for 1000 u32 keys, 110 us for 2^20.  Here the
+// elements live in registers and LDS for all passes of mod.rs:84-169: per pass, stable ranks inside each
 // wave in (round, lane) order, a digit-major / wave-minor scan of the wave counters (count -> prefix,
 // mod.rs:90-120 with chunk == wave), a scatter into LDS and a read back in tile order (mod.rs:121-168); the
-// last pass is written to memory from LDS.  Same bytes as the general path (both are the stable LSD sort).
+// last pass is written to memory from LDS.  Same bytes as the general path (all are the stable LSD sort; a
+// stable partition by the top digit followed by a stable LSD sort of each bucket by the lower digits is the
+// stable sort by the whole key).
 #pragma once
 #include "rsx_device.hpp"
 
 namespace rsx {
 
 struct SmallArgs {
-    void* data;            // n elements, sorted in place
-    uint32_t n;            // 1 .. 512 * KPT
-    uint32_t passes;       // key bytes (T::NUMBER_OF_DIGITS)
+    const void* src;       // n elements (the bucket kernel: the array partitioned by its top digit)
+    void* data;            // where the sorted elements go (may be src)
+    uint32_t n;            // small kernel: 1 .. 512 * KPT
+    uint32_t passes;       // digits to sort by: key bytes (T::NUMBER_OF_DIGITS), one less for the bucket kernel
     uint32_t rank_atomic;  // ranks may come from returned LDS atomics (context self-test)
-    uint32_t map_keys;     // signed / float keys: mapped on load, mapped back on store
+    uint32_t map_load;     // signed / float keys: mapped on load (the bucket kernel finds them mapped)
+    uint32_t map_store;    // ... and mapped back on store
     DigitSpec spec[16];    // digit of pass d of the MAPPED key (flip == 0)
     KeyXform xf;
+    // bucket kernel only
+    const unsigned long long* top_J;  // count matrix of the top digit, [J_REPL][num_regions][256]
+    uint32_t num_regions;
+    uint32_t j32;                     // its entries are 32 bit
+    const uint32_t* mid_flag;         // 1: the first sweep made the buckets; anything else: nothing to do here
+    uint32_t* error;                  // host-visible error word (a bucket larger than the workgroup takes: cannot happen)
 };
 
-template <int ES, int KPT>
-__global__ __launch_bounds__(512) void rsx_small_sort_kernel(const SmallArgs a) {
-    constexpr int WG = 512, NWAVE = WG / WAVE;
+// Sorts elements [0, n) of `src` by `a.passes` digits into `dst` (same index range), n <= WG * KPT.
+template <int ES, int KPT, int WG>
+__device__ __forceinline__ void local_sort(const SmallArgs& a, const Elem<ES>* __restrict__ src, Elem<ES>* __restrict__ dst,
+                                           const uint32_t n, unsigned char* smem) {
+    constexpr int NWAVE = WG / WAVE;
     using E = Elem<ES>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     E* s_elems = reinterpret_cast<E*>(smem);                                              // [WG * KPT]
     uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem + (size_t)WG * KPT * sizeof(E));  // [NWAVE][256]
     uint32_t* s_misc = s_cnt + NWAVE * RADIX;                                             // [NWAVE]
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t n = a.n;
     const uint32_t kp = (n + WG - 1) / WG;          // rounds in use, 1..KPT (wave-uniform, the same for all)
     const uint32_t seg = wave * (WAVE * kp) + lane;  // wave w holds elements [w*64*kp, (w+1)*64*kp), round j at +j*64:
                                                      // (wave, round, lane) order == index order, so ranks are stable
-    E* __restrict__ data = static_cast<E*>(a.data);
     E e[KPT];
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
@@ -42,8 +57,8 @@ __global__ __launch_bounds__(512) void rsx_small_sort_kernel(const SmallArgs a) 
         if ((uint32_t)j < kp) {
             const uint32_t p = seg + (uint32_t)j * WAVE;
             if (p < n) {
-                e[j] = data[p];
-                if (a.map_keys) key_map<ES, false>(e[j], a.xf);
+                e[j] = src[p];
+                if (a.map_load) key_map<ES, false>(e[j], a.xf);
             }
         }
     }
@@ -107,9 +122,55 @@ __global__ __launch_bounds__(512) void rsx_small_sort_kernel(const SmallArgs a) 
     }
     for (uint32_t i = tid; i < n; i += WG) {
         E x = s_elems[i];
-        if (a.map_keys) key_map<ES, true>(x, a.xf);
-        data[i] = x;
+        if (a.map_store) key_map<ES, true>(x, a.xf);
+        dst[i] = x;
     }
+}
+
+template <int ES, int KPT>
+__global__ __launch_bounds__(512) void rsx_small_sort_kernel(const SmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    local_sort<ES, KPT, 512>(a, static_cast<const Elem<ES>*>(a.src), static_cast<Elem<ES>*>(a.data), a.n, smem);
+}
+
+// grid = 256: workgroup v sorts the bucket of top-digit value v, [start_v, start_v + count_v) of the partitioned
+// array, by the lower digits.  The bucket's place comes from the top digit's count matrix (every workgroup sums
+// the columns itself: L2-resident, J_REPL * num_regions loads per thread).
+template <int ES, int KPT>
+__global__ __launch_bounds__(1024) void rsx_bucket_sort_kernel(const SmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.mid_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 1) return;
+    uint64_t* s_red = reinterpret_cast<uint64_t*>(smem);  // [4] partial sums, [4] the bucket's count
+    const uint32_t tid = threadIdx.x, v = blockIdx.x;
+    uint64_t c = 0;
+    if (tid < RADIX) {
+        const uint32_t rows = (uint32_t)J_REPL * a.num_regions;
+        for (uint32_t r0 = 0; r0 < rows; r0 += 8) {  // rows is a multiple of 8 (J_REPL == 8)
+            uint64_t part[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k)
+                part[k] = a.j32 ? (uint64_t)reinterpret_cast<const uint32_t*>(a.top_J)[(r0 + k) * RADIX + tid]
+                                : (uint64_t)a.top_J[(r0 + k) * RADIX + tid];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) c += part[k];
+        }
+        if (tid == v) s_red[4] = c;
+        uint64_t below = tid < v ? c : 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o);
+        if ((tid & 63u) == 0u) s_red[tid >> 6] = below;
+    }
+    __syncthreads();
+    const uint64_t start = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    const uint64_t count = s_red[4];
+    __syncthreads();  // smem is the sort's from here
+    if (count == 0) return;
+    if (count > (uint64_t)1024 * KPT) {  // the first sweep checked every bucket against this capacity
+        if (tid == 0) __hip_atomic_store(a.error, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    local_sort<ES, KPT, 1024>(a, static_cast<const Elem<ES>*>(a.src) + start, static_cast<Elem<ES>*>(a.data) + start,
+                              (uint32_t)count, smem);
 }
 
 }  // namespace rsx

@@ -71,6 +71,51 @@ def test_sizes_around_the_tile(rs, torch, ctx, orc, t):
         assert np.array_equal(_gpu_sort(rs, torch, ctx, raw, d), orc.sort_parallel(raw, lay, 3)), (t, n, dist)
 
 
+BUCKET_KEYS = {2: 28, 4: 28, 8: 14, 12: 9, 16: 7, 24: 4, 32: 3}  # keys per thread of the 1024-thread bucket kernel, by element size
+
+
+def _mid_max(es):
+    return 1024 * BUCKET_KEYS[es] * 256 * 4 // 7
+
+
+@pytest.mark.parametrize("t", [t for t in util.TYPES if util.TYPES[t][2] >= 2])
+def test_middle_sizes(rs, torch, ctx, orc, t):
+    """The middle-size path (bucket split by the top digit + one workgroup per bucket) at its switch points -- the
+    largest size it takes, the first size it does not -- and inside its range with inputs that take the split
+    (uniform, random top byte only) and inputs that refuse it on the device (skewed top digits: LSD passes)."""
+    d = _digits(rs, t)
+    lay = orc.Layout(*util.TYPES[t])
+    mm = _mid_max(d.elem_bytes)
+    rng = np.random.default_rng(777 + d.elem_bytes)
+    cases = [(mm, "uniform"), (mm + 1, "uniform"), (mm // 2 + 3, "highbyte"), (int(rng.integers(mm // 8, mm)), "zipf"),
+             (int(rng.integers(mm // 8, mm)), "two"), (int(rng.integers(mm // 16, mm // 2)), "sorted"),
+             (int(rng.integers(mm // 16, mm // 2)), "uniform"), (int(rng.integers(mm // 16, mm // 2)), "step16")]
+    for i, (n, dist) in enumerate(cases):
+        raw = util.make_input(t, n, dist, seed=1234 + i)
+        assert np.array_equal(_gpu_sort(rs, torch, ctx, raw, d), orc.sort_parallel(raw, lay, 8)), (t, n, dist)
+
+
+@pytest.mark.parametrize("t", ["u32", "(u64,u64)", "i16", "f64"])
+@pytest.mark.parametrize("over", [0, 1])
+def test_middle_size_bucket_capacity_edge(rs, torch, ctx, orc, t, over):
+    """One top-digit bucket holds exactly what a workgroup of the bucket kernel takes (split accepted) or one element
+    more (split refused on the device, LSD passes): same bytes as the oracle either way."""
+    d = _digits(rs, t)
+    es, ko, kb, _kind = util.TYPES[t]
+    lay = orc.Layout(*util.TYPES[t])
+    cap = 1024 * BUCKET_KEYS[es]
+    n = cap + over + 60000
+    raw = util.make_input(t, n, "uniform", seed=99 + over).reshape(n, es)
+    rng = np.random.default_rng(5 + over)
+    top = raw[:, ko + kb - 1]
+    top[:] = rng.integers(0, 255, size=n, dtype=np.uint8)  # 0 .. 254
+    top[top == 0x47] = 0x48
+    pos = rng.choice(n, size=cap + over, replace=False)
+    top[pos] = 0x47                                          # exactly cap (+ over) elements in bucket 0x47 (raw top byte)
+    raw = raw.reshape(-1)
+    assert np.array_equal(_gpu_sort(rs, torch, ctx, raw, d), orc.sort_parallel(raw, lay, 8)), (t, over)
+
+
 @pytest.mark.parametrize("t", list(util.TYPES))
 @pytest.mark.parametrize("dist", util.DISTS)
 def test_distributions(rs, torch, ctx, orc, t, dist):
@@ -307,7 +352,8 @@ ALT_PATHS = [("OPT_TILE_SCHEDULE", 1, "ticketed tiles instead of the static roll
              ("OPT_MAX_REGIONS", 1, "one look-back chain over all tiles"),
              ("OPT_MAX_REGIONS", 32, "32 look-back chains"),
              ("OPT_HOT_LANES", 2, "every tile treated as skewed"),
-             ("OPT_SMALL_SORT", 0, "arrays of at most one tile through the general path")]
+             ("OPT_SMALL_SORT", 0, "arrays of at most one tile through the general path"),
+             ("OPT_MID_SORT", 0, "middle sizes by LSD passes only (no bucket split)")]
 
 
 @pytest.mark.parametrize("opt,value,what", ALT_PATHS)
