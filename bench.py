@@ -246,6 +246,9 @@ def main():
     ap.add_argument("--chunks", type=int, default=4,
                     help="--exchange first: ranges the exchange is cut into so that the local sort of one range runs while "
                          "the next ones are on the links (1 = no overlap)")
+    ap.add_argument("--sub-ranges", type=int, default=4,
+                    help="--exchange first: position sub-ranges the partition pass is cut into so that the first batches are on "
+                         "the links while the later sub-ranges are still being scattered (1 = partition first, then exchange)")
     ap.add_argument("--cpu-ladder", action="store_true",
                     help="N=1: also time the reference's CPU ladder radix_sort0..5 (oracle restatement) on this host: extra.cpu_ladder")
     args = ap.parse_args()
@@ -334,8 +337,10 @@ def main():
     else:
         dist.init_process_group("gloo")
     sorter = ShardedRadixSort()
+    agree = dist.new_group(backend="gloo")  # host-side agreement between the ranks (never carries data)
     stream = torch.cuda.current_stream().cuda_stream
     cdev = "cuda" if args.backend == "nccl" else "cpu"
+    state = {"exchange": args.exchange, "note": ""}
 
     def run_sharded(wl):
         t, logn, gen, param, desc = WORKLOADS[wl]
@@ -351,12 +356,37 @@ def main():
         def fill(i, b):
             ctx.generate_device(b.data_ptr(), n, d, gen_id(rs, gen), 0x5EED0000 + i, param, rank * n, stream)
 
-        run = {"first": lambda b: sorter.sort_exchange_first(b, d, n_per_rank, chunks=args.chunks),
-               "one": lambda b: sorter.sort_one_exchange(b, d, n_per_rank),
-               "per-pass": lambda b: sorter.sort(b, d, n_per_rank)}[args.exchange]
-        for i in range(args.warmup):
+        def run(b):  # -> the tensor that holds the sorted slice (the donated form may hand back another buffer)
+            if state["exchange"] == "first":
+                return sorter.sort_exchange_first(b, d, n_per_rank, chunks=args.chunks, sub_ranges=args.sub_ranges, donate=True)
+            if state["exchange"] == "one":
+                sorter.sort_one_exchange(b, d, n_per_rank)
+            else:
+                sorter.sort(b, d, n_per_rank)
+            return b
+
+        for i in range(max(1, args.warmup)):
             fill(1000 + i, bufs[0])
-            run(bufs[0])
+            ok, why = 1, ""
+            try:
+                bufs[0] = run(bufs[0])
+                torch.cuda.synchronize()
+            except AssertionError:
+                raise
+            except Exception as e:  # noqa: BLE001
+                ok, why = 0, repr(e)
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=agree)
+            if flag.item() == 0 and state["exchange"] == "first":
+                # the batched point-to-point exchange has never run between two real GPUs in the builder's hands: if it
+                # fails on this node, every rank falls back to the schedule built on ONE all_to_all_single
+                state["exchange"] = "one"
+                state["note"] = "exchange-first raised on some rank (%s): fell back to --exchange one" % (why or "another rank")
+                fill(1000 + i, bufs[0])
+                run(bufs[0])
+                torch.cuda.synchronize()
+            elif flag.item() == 0:
+                raise SystemExit("rank %d: sort failed: %s" % (rank, why or "on another rank"))
         done, elapsed = 0, 0.0
         while done < args.steps:  # pool-sized rounds (pool == steps unless memory is short)
             k = min(pool, args.steps - done)
@@ -368,7 +398,7 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(k):
-                run(bufs[i])
+                bufs[i] = run(bufs[i])
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -385,7 +415,7 @@ def main():
         total = n * world
         return {"workload": wl, "desc": desc, "type": t, "n_total": total, "n_per_gpu": n, "d": d, "gen": gen, "ms": ms,
                 "gkeys_per_s": total / ms / 1e6, "algorithmic_gbps": d.key_bytes * 2 * total * d.elem_bytes / ms / 1e6,
-                "branch": sorter.last_branch}
+                "branch": sorter.last_branch + ("; " + state["note"] if state["note"] else ""), "exchange": state["exchange"]}
 
     r = run_sharded(args.workload)
     extra = {}
@@ -411,9 +441,9 @@ def main():
                        "generator": r["gen"],
                        "exchange": {"first": "partition by the top digit in %d sub-ranges + all-gather(256 x u64) + exact cuts inside boundary "
                                              "buckets (device-side search, one D2H) + ONE all-to-all-v in %d batches, each range sorted while "
-                                             "the next is on the links" % (args.chunks, args.chunks),
+                                             "the next is on the links" % (args.sub_ranges, args.chunks),
                                     "one": "local sort + 256-way splitter search (1 all-reduce per digit) + ONE all-to-all-v + local sort",
-                                    "per-pass": "per-pass all-gather(256 x u64) + all-to-all-v"}[args.exchange] +
+                                    "per-pass": "per-pass all-gather(256 x u64) + all-to-all-v"}[r["exchange"]] +
                                    (" (RCCL)" if args.backend == "nccl" else " (gloo, host-staged: rehearsal only)"),
                        "exchange_branch": r["branch"],
                        "verified": "slices sorted and stable, multiset checksum all-reduced, rank-boundary keys in order"},

@@ -48,6 +48,39 @@ class HipBackend:
         s = self.torch.cuda.current_stream().cuda_stream
         self.ctx.partition_device(src.data_ptr(), dst.data_ptr(), n, d, digit, hist.data_ptr(), s)
 
+    def partition_count(self, src, n: int, d: RadixDigits, digit: int, nsub: int) -> np.ndarray:
+        """Digit counts of every position sub-range of the slice (rsx_partition_count_device): numpy int64 [nsub, 256]."""
+        hist = self.torch.zeros(nsub * 256, dtype=self.torch.int64, device=self.device)
+        s = self.torch.cuda.current_stream().cuda_stream
+        self.ctx.partition_count_device(src.data_ptr(), n, d, digit, nsub, hist.data_ptr(), s)
+        return hist.cpu().numpy().reshape(nsub, 256)
+
+    def partition_scatter(self, src, dst, n: int, d: RadixDigits, digit: int, nsub: int, k: int):
+        """Stable partition of sub-range k by `digit` into the same positions of dst (rsx_partition_scatter_device)."""
+        s = self.torch.cuda.current_stream().cuda_stream
+        self.ctx.partition_scatter_device(src.data_ptr(), dst.data_ptr(), n, d, digit, nsub, k, s)
+
+    def search_cuts_device(self, bb, nbb: int, d: RadixDigits, beg, end, pre_lo, pre_hi, rank_in, top_digit: int, all_reduce):
+        """ShardedRadixSort._search_cuts with the key prefix kept on the device: per digit one count kernel, the ranks'
+        all-reduce (`all_reduce(tensor)`, in place) and one pick kernel, all stream-ordered; ONE copy to the host at the end."""
+        t = self.torch
+        nb = len(rank_in)
+        rng = np.stack([np.asarray(beg, dtype=np.uint64), np.asarray(end, dtype=np.uint64)], axis=1).reshape(-1)
+        pre = np.stack([np.asarray(pre_lo, dtype=np.uint64), np.asarray(pre_hi, dtype=np.uint64)], axis=1).reshape(-1)
+        host = np.concatenate([rng, pre, np.asarray(rank_in, dtype=np.int64).view(np.uint64)]).view(np.int64)
+        dev = t.from_numpy(host.copy()).to(self.device)
+        ranges, prefix, rank = dev[:2 * nb], dev[2 * nb:4 * nb], dev[4 * nb:]
+        less = t.empty(nb * 256, dtype=t.int64, device=self.device)
+        out = t.empty(2 * nb, dtype=t.int64, device=self.device)
+        s = t.cuda.current_stream().cuda_stream
+        for digit in range(top_digit - 1, -1, -1):
+            self.ctx.splitter_count_device(bb.data_ptr(), nbb, d, ranges.data_ptr(), prefix.data_ptr(), nb, digit, less.data_ptr(), s)
+            all_reduce(less)
+            self.ctx.splitter_pick_device(less.data_ptr(), rank.data_ptr(), prefix.data_ptr(), nb, digit, s)
+        self.ctx.bounds_ranges_device(bb.data_ptr(), nbb, d, prefix.data_ptr(), ranges.data_ptr(), nb, out.data_ptr(), s)
+        o = out.cpu().numpy()
+        return o[:nb].copy(), o[nb:].copy()
+
     def segmented_copy(self, src, dst, elem_bytes: int, src_off, dst_off, length, nseg: int):
         s = self.torch.cuda.current_stream().cuda_stream
         self.ctx.segmented_copy_device(src.data_ptr(), dst.data_ptr(), elem_bytes, src_off.data_ptr(),
@@ -160,6 +193,9 @@ class ShardedRadixSort:
         # gloo moves host memory only: device slices are staged through the host for the two
         # collectives (test rigs: several ranks on one GPU).  RCCL ("nccl") runs device to device.
         self.host_staged = dist.get_backend(group) == "gloo"
+        # the small collectives of the planning steps go through a group of their own: on RCCL a communicator is a
+        # stream, and the data group's is full of queued exchange batches while the cuts are being searched
+        self.ctl = dist.new_group(backend=dist.get_backend(group)) if group is None and self.world > 1 else group
         # RSX_SHARD_TIMING=1: rank 0 prints where a sort_exchange_first call spends its time (each mark
         # synchronises the device: diagnostics only, it serialises what the schedule overlaps)
         import os
@@ -200,12 +236,12 @@ class ShardedRadixSort:
         self.dist.all_gather(allt, t, group=self.group)
         return [int(a.item()) for a in allt]
 
-    def _all_reduce_sum(self, a: np.ndarray, device) -> np.ndarray:
+    def _all_reduce_sum(self, a: np.ndarray, device, ctl: bool = False) -> np.ndarray:
         import torch
         t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64))
         if not self.host_staged:
             t = t.to(device)
-        self.dist.all_reduce(t, group=self.group)
+        self.dist.all_reduce(t, group=self.ctl if ctl else self.group)
         return t.cpu().numpy()
 
     def sort_one_exchange(self, x, d: RadixDigits, n_per_rank: Optional[List[int]] = None):
@@ -281,17 +317,18 @@ class ShardedRadixSort:
             be.sort(x, tmp, n_local, d)
         be.finish()
 
-    def _all_gather_i64(self, a: np.ndarray, device) -> np.ndarray:
-        """[G, len(a)] int64: every rank's vector."""
+    def _all_gather_i64(self, a: np.ndarray, device, ctl: bool = False) -> np.ndarray:
+        """[G, len(a)] int64: every rank's vector (ctl: on the control group)."""
         import torch
+        grp = self.ctl if ctl else self.group
         src = torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64))
         if self.host_staged:
             out = [torch.zeros_like(src) for _ in range(self.world)]
-            self.dist.all_gather(out, src, group=self.group)
+            self.dist.all_gather(out, src, group=grp)
             return torch.stack(out).numpy()
         src = src.to(device)
         out = [torch.zeros_like(src) for _ in range(self.world)]
-        self.dist.all_gather(out, src, group=self.group)
+        self.dist.all_gather(out, src, group=grp)
         return torch.stack(out).cpu().numpy()
 
     def _exchange(self, send, recv, send_counts, recv_counts, es: int):
@@ -305,71 +342,194 @@ class ShardedRadixSort:
             self.dist.all_to_all_single(recv, send, output_split_sizes=(recv_counts * es).tolist(),
                                         input_split_sizes=(send_counts * es).tolist(), group=self.group)
 
-    def sort_exchange_first(self, x, d: RadixDigits, n_per_rank: Optional[List[int]] = None, chunks: int = 1):
-        """Same contract as `sort`.  Partition by the top digit, exchange once, sort once.
+    def _all_reduce_dev(self, t):
+        """In-place sum over the ranks of a device tensor, on the control group (the data group's stream may be
+        full of queued exchange batches); host-staged under gloo."""
+        if self.host_staged and t.is_cuda:
+            h = t.cpu()
+            self.dist.all_reduce(h, group=self.ctl)
+            t.copy_(h)
+        else:
+            self.dist.all_reduce(t, group=self.ctl)
+        return t
 
-        chunks > 1 pipelines the exchange with the local sort: what a rank receives is cut into `chunks`
-        consecutive ranges of top-digit values of about equal size; the pieces of range c travel as one
-        batch of sends/receives, and range c is sorted (it is final: the ranges are ordered by key) while
-        the batches behind it are still on the links.  xGMI moves a slice more slowly than the GPU sorts
-        it, so this hides the local sort behind the exchange but for the last range."""
+    def _search_cuts(self, bb, nbb: int, d: RadixDigits, beg, end, pre_lo, pre_hi, rank_in, top_digit: int):
+        """Exact cut of sorted runs at global ranks.  Boundary i: this rank's run [beg[i], end[i]) of `bb` (sorted by
+        mapped key); the union of the ranks' runs is cut below its rank_in[i]-th element in (key, rank, position) order;
+        the digits from `top_digit` up are already fixed in (pre_lo[i], pre_hi[i]).  Returns (less, leq): this rank's
+        counts of keys below / not above the boundary key, [nb] each.  One 256-way step per digit (mod.rs:110-120's
+        cursors, found by search instead of by scan); with the HIP backend the steps run on the device, stream-ordered
+        (count kernel -> all-reduce -> pick kernel), and the host reads ONE result at the end."""
         be = self.backend
+        nb = len(rank_in)
+        if hasattr(be, "search_cuts_device"):
+            return be.search_cuts_device(bb, nbb, d, beg, end, pre_lo, pre_hi, rank_in, top_digit, self._all_reduce_dev)
+        pre_lo, pre_hi = pre_lo.copy(), pre_hi.copy()
+        j256 = np.arange(256, dtype=np.uint64)
+        for digit in range(top_digit - 1, -1, -1):
+            lo = np.repeat(pre_lo[:, None], 256, axis=1)
+            hi = np.repeat(pre_hi[:, None], 256, axis=1)
+            if digit < 8:
+                lo |= j256[None, :] << np.uint64(8 * digit)
+            else:
+                hi |= j256[None, :] << np.uint64(8 * (digit - 8))
+            less, _ = be.bounds_ranges(bb, nbb, d, lo.reshape(-1), hi.reshape(-1), np.repeat(beg, 256), np.repeat(end, 256))
+            gl = self._all_reduce_sum(less, bb.device, ctl=True).reshape(nb, 256)
+            j = ((gl <= rank_in[:, None]).sum(axis=1) - 1).astype(np.uint64)
+            if digit < 8:
+                pre_lo |= j << np.uint64(8 * digit)
+            else:
+                pre_hi |= j << np.uint64(8 * (digit - 8))
+        return be.bounds_ranges(bb, nbb, d, pre_lo, pre_hi, beg, end)
+
+    def sort_exchange_first(self, x, d: RadixDigits, n_per_rank: Optional[List[int]] = None, chunks: int = 1,
+                            sub_ranges: int = 1, donate: bool = False):
+        """Same contract as `sort`: partition by the top digit, exchange once, sort once.  Returns the tensor that
+        holds the sorted slice: `x` itself, unless `donate` (below).
+
+        chunks (C) pipelines the exchange with the local sort at the RECEIVER: what a rank receives is cut into C
+        consecutive ranges of top-digit values of about equal size; a range is final once it is sorted (the ranges
+        are ordered by key), so it is sorted while the ranges behind it are still on the links.
+        sub_ranges (K) pipelines the partition pass with the exchange at the SENDER: the slice is partitioned in K
+        position sub-ranges (rsx_partition_count_device / rsx_partition_scatter_device); the batches go out range-major
+        and sub-range-minor, so the first range's pieces of sub-range 0 are on the links while sub-range 1 is still
+        being scattered.  The buckets a slice boundary cuts through travel last: every rank merges its K pieces of
+        such a bucket, sorts them, and the exact cut is found by a digit-wise search on the device.
+        With K > 1 the receive buffer cannot be `x` (still being read by the scatters): the result lands in a second
+        buffer, which is copied back into `x` -- or, with `donate`, handed to the caller in exchange for `x`."""
+        import torch
+        dist, be = self.dist, self.backend
         es, G, me = d.elem_bytes, self.world, self.rank
         n_local = x.numel() // es
         if n_per_rank is None:
             n_per_rank = self._gather_counts(n_local, x.device)
         n_per_rank = np.asarray(n_per_rank, dtype=np.int64)
         assert n_per_rank[me] == n_local
+        K = max(1, min(int(sub_ranges), 16))
+        C = max(1, int(chunks))
+        staged = self.host_staged and x.is_cuda
         bounds = np.concatenate(([0], np.cumsum(n_per_rank)))
-        part = self._buf("part", n_local * es)
         top = d.key_bytes - 1
+        part = self._buf("part", n_local * es)
+        recv = x if K == 1 else self._buf("recv", n_local * es)
+        self.last_branch = f"exchange-first: {K} sub-range(s) x {C} range(s), " + ("p2p batches" if G > 1 else "single rank")
         self._mark("start")
-        # 1. one stable partition pass by the most significant digit (count + scatter, mod.rs:90-168)
-        hist = be.zeros_u64(256)
-        if n_local:
-            be.partition(x, part, n_local, d, top, hist)
-        self._mark("partition")
-        H = self._all_gather_i64(hist.cpu().numpy() if hasattr(hist, "cpu") else np.asarray(hist), x.device)  # [G][256]
-        self._mark("gather-counts")
-        # 2. the buckets in global order (digit-major, rank-minor: mod.rs:110-120 with chunk == rank)
-        lstart = np.concatenate([np.zeros((G, 1), np.int64), np.cumsum(H, axis=1)], axis=1)  # [G][257]
+        # 1. count phase of the partition pass per sub-range (mod.rs:90-109 with chunk == sub-range of a rank)
+        HH = self._all_gather_i64(be.partition_count(x, n_local, d, top, K).reshape(-1), x.device).reshape(G, K, 256)
+        self._mark("count + gather")
+        H = HH.sum(axis=1)                                                       # [G][256]
+        lst = np.concatenate([np.zeros((G, K, 1), np.int64), np.cumsum(HH, axis=2)], axis=2)  # bucket v inside block (g, k)
+        sk = np.array([[(int(n_per_rank[g]) * k) // K for k in range(K + 1)] for g in range(G)], dtype=np.int64)
         tot = H.sum(axis=0)
-        gstart = np.concatenate(([0], np.cumsum(tot)))  # [257]
-        split = np.zeros((G, G + 1), dtype=np.int64)
-        split[:, G] = n_per_rank
-        inside = []  # (boundary, bucket) for boundaries strictly inside a bucket
+        gstart = np.concatenate(([0], np.cumsum(tot)))                           # [257] buckets in global order
+        assert gstart[256] == bounds[G]
+        # 2. which buckets a slice boundary cuts through (they are cut exactly and travel last); who owns the others
+        inside = []
         for b in range(G - 1):
             T = bounds[b + 1]
-            v = int(np.searchsorted(gstart[1:], T, side="right"))  # first bucket that ends above T
-            if v == 256:
-                split[:, b + 1] = n_per_rank
-            elif gstart[v] == T:
-                split[:, b + 1] = lstart[:, v]
-            else:
+            v = int(np.searchsorted(gstart[1:], T, side="right"))
+            if v < 256 and gstart[v] < T:
                 inside.append((b, v))
-        # boundary buckets: every rank sorts its piece (tmp piece in place, the old slice as scratch)
-        def piece(buf, v):
-            return buf[lstart[me, v] * es: lstart[me, v + 1] * es]
-        # (ONE sort over the concatenation of the pieces rather than one small sort per bucket: a piece holds one
-        # top-digit value, so sorting them together by the whole key keeps every piece where it is and sorts
-        # it -- and a small sort is mostly launch overhead: ~0.25 ms each, G-1 of them)
-        vs = [v for v in sorted({v for _, v in inside}) if lstart[me, v + 1] - lstart[me, v] > 0]
-        if len(vs) == 1:
-            ln = int(lstart[me, vs[0] + 1] - lstart[me, vs[0]])
-            if ln > 1:
-                be.sort(piece(part, vs[0]), piece(x, vs[0]), ln, d)
-        elif vs:
-            import torch
-            both = torch.cat([piece(part, v) for v in vs])
-            total = both.numel() // es
-            be.sort(both, self._buf("sort_scratch", total * es), total, d)
-            off = 0
+        Bset = sorted({v for _, v in inside})
+        isB = np.zeros(256, dtype=bool)
+        isB[Bset] = True
+        owner = np.searchsorted(bounds[1:], gstart[:256], side="right")          # rank whose range holds the bucket's start
+        owner = np.minimum(owner, G - 1)
+        chunk_of = np.zeros(256, dtype=np.int64)
+        for h in range(G):
+            vs = [v for v in range(256) if not isB[v] and owner[v] == h and tot[v] > 0]
+            whole = int(tot[vs].sum()) if vs else 0
+            run = 0
             for v in vs:
-                ln = int(lstart[me, v + 1] - lstart[me, v]) * es
-                piece(part, v).copy_(both[off:off + ln])
-                off += ln
-        self._mark("sort-boundary-buckets")
+                chunk_of[v] = min(C - 1, (run * C) // max(1, whole))
+                run += int(tot[v])
+        # 3. layout of every rank's slice after the exchange: regions in bucket order -- a boundary bucket's share
+        #    ("B", v) or a range of whole buckets ("W", c); every region is sorted by itself once it is complete
+        def regions_of(h):
+            regs, off = [], 0
+            for v in range(256):
+                if tot[v] == 0:
+                    continue
+                if isB[v]:
+                    ln = int(min(gstart[v + 1], bounds[h + 1]) - max(gstart[v], bounds[h]))
+                    if ln > 0:
+                        regs.append([("B", v), off, ln])
+                        off += ln
+                elif owner[v] == h:
+                    key = ("W", int(chunk_of[v]))
+                    if regs and regs[-1][0] == key:
+                        regs[-1][2] += int(tot[v])
+                    else:
+                        regs.append([key, off, int(tot[v])])
+                    off += int(tot[v])
+            assert off == n_per_rank[h], (h, off, n_per_rank[h])
+            return {r[0]: (r[1], r[2]) for r in regs}
+        my_regs = regions_of(me)
+
+        def piece(buf, off, ln):
+            return buf[int(off) * es:int(off + ln) * es]
+
+        # whole buckets: size_w[g][k][h][c] elements of block (g, k) go to rank h in range c, one contiguous piece
+        size_w = np.zeros((G, K, G, C), dtype=np.int64)
+        first_v = np.full((G, C), -1, dtype=np.int64)
+        for v in range(256):
+            if isB[v] or tot[v] == 0:
+                continue
+            h, c = int(owner[v]), int(chunk_of[v])
+            size_w[:, :, h, c] += HH[:, :, v]
+            if first_v[h, c] < 0:
+                first_v[h, c] = v
+
+        def batch_whole(c, k):
+            """(ops, landing, local copies) of range c / sub-range k: my pieces out, the other ranks' pieces in."""
+            ops, landing = [], []
+            for step in range(G):
+                h, g = (me + step) % G, (me - step) % G
+                ln = int(size_w[me, k, h, c])
+                if ln:
+                    src = piece(part, sk[me, k] + lst[me, k, first_v[h, c]], ln)
+                    if h == me:
+                        dst_off = my_regs[("W", c)][0] + int(size_w[:me, :, me, c].sum()) + int(size_w[me, :k, me, c].sum())
+                        piece(recv, dst_off, ln).copy_(src)
+                    else:
+                        ops.append(dist.P2POp(dist.isend, src.cpu() if staged else src, h, group=self.group))
+                ln = int(size_w[g, k, me, c])
+                if ln and g != me:
+                    dst_off = my_regs[("W", c)][0] + int(size_w[:g, :, me, c].sum()) + int(size_w[g, :k, me, c].sum())
+                    dst = piece(recv, dst_off, ln)
+                    if staged:
+                        host = torch.empty(dst.numel(), dtype=torch.uint8)
+                        landing.append((dst, host))
+                        dst = host
+                    ops.append(dist.P2POp(dist.irecv, dst, g, group=self.group))
+            return (dist.batch_isend_irecv(ops) if ops else []), landing
+
+        # 4. scatter phase per sub-range (mod.rs:110-168); range 0 of a sub-range goes out as soon as it is scattered
+        works = {}
+        for k in range(K):
+            if n_local:
+                be.partition_scatter(x, part, n_local, d, top, K, k)
+            works[(0, k)] = batch_whole(0, k)
+        for c in range(1, C):
+            for k in range(K):
+                works[(c, k)] = batch_whole(c, k)
+        self._mark("scatter + batches issued")
+        # 5. boundary buckets: merge my K pieces of each, sort, cut exactly, exchange the shares
+        bworks = None
         if inside:
+            myB = [v for v in Bset if H[me, v] > 0]
+            if myB:
+                bb = torch.cat([piece(part, sk[me, k] + lst[me, k, v], HH[me, k, v]) for v in myB for k in range(K)])
+            else:
+                bb = part[:0]
+            nbb = bb.numel() // es
+            if nbb > 1:  # one sort: the buckets differ in their top digit, so they stay apart and in order
+                be.sort(bb, self._buf("bb_scratch", nbb * es), nbb, d)
+            boff = {}
+            o = 0
+            for v in Bset:
+                boff[v] = o
+                o += int(H[me, v])
             nb = len(inside)
             rank_in = np.array([bounds[b + 1] - gstart[v] for b, v in inside], dtype=np.int64)
             pre_lo = np.zeros(nb, dtype=np.uint64)
@@ -379,117 +539,77 @@ class ShardedRadixSort:
                     pre_lo[i] = np.uint64(v) << np.uint64(8 * top)
                 else:
                     pre_hi[i] = np.uint64(v) << np.uint64(8 * (top - 8))
-            j256 = np.arange(256, dtype=np.uint64)
-            # every boundary's queries are answered inside its own bucket's sorted piece: one call per digit
-            beg = np.array([lstart[me, v] for _, v in inside], dtype=np.uint64)
-            end = np.array([lstart[me, v + 1] for _, v in inside], dtype=np.uint64)
-            for digit in range(top - 1, -1, -1):
-                lo = np.repeat(pre_lo[:, None], 256, axis=1)
-                hi = np.repeat(pre_hi[:, None], 256, axis=1)
-                if digit < 8:
-                    lo |= j256[None, :] << np.uint64(8 * digit)
-                else:
-                    hi |= j256[None, :] << np.uint64(8 * (digit - 8))
-                less, _ = be.bounds_ranges(part, n_local, d, lo.reshape(-1), hi.reshape(-1), np.repeat(beg, 256), np.repeat(end, 256))
-                gl = self._all_reduce_sum(less, x.device).reshape(nb, 256)
-                j = ((gl <= rank_in[:, None]).sum(axis=1) - 1).astype(np.uint64)
-                if digit < 8:
-                    pre_lo |= j << np.uint64(8 * digit)
-                else:
-                    pre_hi |= j << np.uint64(8 * (digit - 8))
-            l_me, q_me = be.bounds_ranges(part, n_local, d, pre_lo, pre_hi, beg, end)
-            mine = np.stack([l_me, q_me]).astype(np.int64)
-            M = self._all_gather_i64(mine.reshape(-1), x.device).reshape(G, 2, nb)
+            beg = np.array([boff[v] for _, v in inside], dtype=np.uint64)
+            end = np.array([boff[v] + int(H[me, v]) for _, v in inside], dtype=np.uint64)
+            l_me, q_me = self._search_cuts(bb, nbb, d, beg, end, pre_lo, pre_hi, rank_in, top)
+            M = self._all_gather_i64(np.stack([l_me, q_me]).astype(np.int64).reshape(-1), x.device, ctl=True).reshape(G, 2, nb)
             less, eq = M[:, 0, :], M[:, 1, :] - M[:, 0, :]
             need = rank_in - less.sum(axis=0)  # elements equal to the boundary key that go below the cut
             before = np.cumsum(eq, axis=0) - eq
-            take = np.clip(need[None, :] - before, 0, eq)  # ties: lower rank first (stability)
-            for i, (b, v) in enumerate(inside):
-                split[:, b + 1] = lstart[:, v] + less[:, i] + take[:, i]
-        send_counts = np.diff(split[me])
-        recv_counts = split[:, me + 1] - split[:, me]
-        assert send_counts.sum() == n_local and recv_counts.sum() == n_local, (send_counts, recv_counts)
-        self._mark("exact-cuts")
-        if chunks > 1 and G > 1:
-            self._pipelined_exchange_and_sort(x, part, d, split, lstart, chunks)
-            be.finish()
-            self._mark("exchange+sort (pipelined)")
-            self._report()
-            return
-        # 3. the one exchange, straight back into the slice; 4. one local sort
-        self._exchange(part, x, send_counts, recv_counts, es)
-        self._mark("exchange")
-        if n_local > 1:
-            be.sort(x, part, n_local, d)
-        be.finish()
-        self._mark("sort")
-        self._report()
-
-    def _pipelined_exchange_and_sort(self, x, part, d: RadixDigits, split: np.ndarray, lstart: np.ndarray, chunks: int):
-        """Steps 3 and 4 of `sort_exchange_first`, overlapped.  split[g][h]..split[g][h+1] of rank g's
-        partitioned slice goes to rank h; lstart[g][v] is where top-digit bucket v starts in it.  Every rank
-        derives the same plan from these two tables."""
-        import torch
-        dist, be = self.dist, self.backend
-        es, G, me = d.elem_bytes, self.world, self.rank
-        n_local = x.numel() // es
-        # cnt[g][h][v]: elements of rank g's bucket v that go to rank h (overlap of the bucket with h's range)
-        lo = np.maximum(lstart[:, None, :-1], split[:, :-1, None])
-        hi = np.minimum(lstart[:, None, 1:], split[:, 1:, None])
-        cnt = np.clip(hi - lo, 0, None)  # [G][G][256]
-        # ranges of top-digit values, per destination, of about equal size: boundaries by cumulative count
-        tot = cnt.sum(axis=0)  # [h][v]
-        cum = np.cumsum(tot, axis=1)
-        edges = np.zeros((G, chunks + 1), dtype=np.int64)  # bucket index where chunk c of destination h starts
-        for h in range(G):
-            n_h = cum[h, -1]
-            for c in range(1, chunks):
-                edges[h, c] = int(np.searchsorted(cum[h], (n_h * c) // chunks, side="right"))
-            edges[h, chunks] = 256
-            edges[h] = np.maximum.accumulate(edges[h])
-        # size[g][h][c]: what g sends to h in batch c (one contiguous piece: buckets are in order inside g's range for h)
-        size = np.zeros((G, G, chunks), dtype=np.int64)
-        for h in range(G):
-            for c in range(chunks):
-                size[:, h, c] = cnt[:, h, edges[h, c]:edges[h, c + 1]].sum(axis=1)
-        send_off = split[me, :-1, None] + np.cumsum(size[me], axis=1) - size[me]  # [h][c] offsets in `part`
-        csize = size[:, me, :].sum(axis=0)  # my chunk sizes
-        coff = np.concatenate(([0], np.cumsum(csize)))
-        recv_off = coff[None, :-1] + np.cumsum(size[:, me, :], axis=0) - size[:, me, :]  # [g][c] offsets in x
-        assert coff[-1] == n_local
-        scratch = self._buf("sort_scratch", int(csize.max()) * es if n_local else 0)
-
-        def piece(buf, off, ln):
-            return buf[int(off) * es:int(off + ln) * es]
-
-        staged = self.host_staged and x.is_cuda
-        works = []
-        for c in range(chunks):
+            cut = less + np.clip(need[None, :] - before, 0, eq)  # [G][nb]; ties: lower rank first (stability)
+            self._mark("boundary buckets: sort + exact cuts")
+            # share[g][v][h] = (offset in g's sorted bucket v, length) going to rank h
             ops, landing = [], []
-            for k in range(1, G):  # ring order: every link starts busy
-                h, g = (me + k) % G, (me - k) % G
-                if size[me, h, c]:
-                    src = piece(part, send_off[h, c], size[me, h, c])
-                    ops.append(dist.P2POp(dist.isend, src.cpu() if staged else src, h, group=self.group))
-                if size[g, me, c]:
-                    dst = piece(x, recv_off[g, c], size[g, me, c])
-                    if staged:
-                        host = torch.empty(dst.numel(), dtype=torch.uint8)
-                        landing.append((dst, host))
-                        dst = host
-                    ops.append(dist.P2POp(dist.irecv, dst, g, group=self.group))
-            reqs = dist.batch_isend_irecv(ops) if ops else []
-            if size[me, me, c]:  # my own piece: a local copy
-                piece(x, recv_off[me, c], size[me, me, c]).copy_(piece(part, send_off[me, c], size[me, me, c]))
-            works.append((reqs, landing))
-        for c in range(chunks):
-            reqs, landing = works[c]
-            for r in reqs:
-                r.wait()  # (RCCL: the compute stream waits, not the host)
-            for dst, host in landing:
-                dst.copy_(host)
-            if csize[c] > 1:
-                be.sort(piece(x, coff[c], csize[c]), scratch[:int(csize[c]) * es], int(csize[c]), d)
+            for v in Bset:
+                bs = [i for i, (_, vv) in enumerate(inside) if vv == v]  # boundaries inside v, ascending
+                b0 = inside[bs[0]][0]
+                edges = np.concatenate([np.zeros((G, 1), np.int64), cut[:, bs], H[:, v:v + 1]], axis=1)  # [G][m + 2]
+                for j in range(len(bs) + 1):
+                    h = b0 + j  # the ranks b0 .. b0 + m share bucket v
+                    ln_g = edges[:, j + 1] - edges[:, j]
+                    assert (ln_g >= 0).all()
+                    if h == me:
+                        if ("B", v) not in my_regs:
+                            assert ln_g.sum() == 0
+                            continue
+                        roff, rlen = my_regs[("B", v)]
+                        assert ln_g.sum() == rlen, (v, ln_g.sum(), rlen)
+                        for g in range(G):
+                            if not ln_g[g]:
+                                continue
+                            dst = piece(recv, roff + int(ln_g[:g].sum()), ln_g[g])
+                            if g == me:
+                                dst.copy_(piece(bb, boff[v] + edges[me, j], ln_g[me]))
+                            else:
+                                if staged:
+                                    host = torch.empty(dst.numel(), dtype=torch.uint8)
+                                    landing.append((dst, host))
+                                    dst = host
+                                ops.append(dist.P2POp(dist.irecv, dst, g, group=self.group))
+                    elif ln_g[me]:
+                        src = piece(bb, boff[v] + edges[me, j], ln_g[me])
+                        ops.append(dist.P2POp(dist.isend, src.cpu() if staged else src, h, group=self.group))
+            # one batch: per peer the sends and the receives pair up in bucket order on both sides
+            bworks = ((dist.batch_isend_irecv(ops) if ops else []), landing)
+        # 6. every region is sorted as soon as it is complete (stable LSD sort of mod.rs:84-169 by the whole key)
+        scratch_len = max([ln for _, ln in my_regs.values()], default=0)
+        scratch = self._buf("sort_scratch", scratch_len * es)
+
+        def finish(reqs_landing, key):
+            for reqs, landing in reqs_landing:
+                for r in reqs:
+                    r.wait()  # (RCCL: the compute stream waits, not the host)
+                for dst, host in landing:
+                    dst.copy_(host)
+            if key in my_regs:
+                off, ln = my_regs[key]
+                if ln > 1:
+                    be.sort(piece(recv, off, ln), scratch[:ln * es], ln, d)
+        for c in range(C):
+            finish([works[(c, k)] for k in range(K)], ("W", c))
+        if bworks is not None:
+            finish([bworks], None)
+            for v in Bset:
+                finish([], ("B", v))
+        be.finish()
+        self._mark("exchange + sorts")
+        self._report()
+        if recv is not x:
+            if donate:
+                self._bufs["recv"] = x  # the caller's buffer is our scratch from now on
+                return recv
+            x.copy_(recv)
+        return x
 
     # ---- verification of a sharded result (bench.py's N > 1 check and the tests share it) ----------------
     def checksum(self, x, d: RadixDigits) -> int:

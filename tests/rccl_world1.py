@@ -12,7 +12,7 @@ ctx = rs.default_context(0)
 d = rs.PRIMITIVES["u32"]; n = 1 << 24
 s = ShardedRadixSort()
 out = torch.zeros(3, dtype=torch.int64, device="cuda")
-for name, run in (("first", lambda b: s.sort_exchange_first(b, d, [n], chunks=4)), ("one", lambda b: s.sort_one_exchange(b, d, [n])), ("per-pass", lambda b: s.sort(b, d, [n]))):
+for name, run in (("first", lambda b: s.sort_exchange_first(b, d, [n], chunks=4)), ("overlapped", lambda b: s.sort_exchange_first(b, d, [n], chunks=4, sub_ranges=4)), ("one", lambda b: s.sort_one_exchange(b, d, [n])), ("per-pass", lambda b: s.sort(b, d, [n]))):
     x = torch.empty(n * 4, dtype=torch.uint8, device="cuda")
     ctx.generate_device(x.data_ptr(), n, d, rs.GEN_UNIFORM, 5)
     run(x); torch.cuda.synchronize()

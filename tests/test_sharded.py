@@ -43,6 +43,21 @@ class OracleBackend:
         dst.numpy()[: n * d.elem_bytes] = out
         hist.numpy()[:] = h.astype(np.int64)
 
+    def partition_count(self, src, n, d, digit, nsub):
+        lay = self.orc.Layout(d.elem_bytes, d.key_offset, d.key_bytes, d.key_kind)
+        out = np.zeros((nsub, 256), dtype=np.int64)
+        for k in range(nsub):
+            a, b = (n * k) // nsub, (n * (k + 1)) // nsub
+            if b > a:
+                out[k] = self.orc.partition_pass(src.numpy()[a * d.elem_bytes:b * d.elem_bytes].copy(), lay, digit)[1].astype(np.int64)
+        return out
+
+    def partition_scatter(self, src, dst, n, d, digit, nsub, k):
+        lay = self.orc.Layout(d.elem_bytes, d.key_offset, d.key_bytes, d.key_kind)
+        a, b = (n * k) // nsub, (n * (k + 1)) // nsub
+        if b > a:
+            dst.numpy()[a * d.elem_bytes:b * d.elem_bytes] = self.orc.partition_pass(src.numpy()[a * d.elem_bytes:b * d.elem_bytes].copy(), lay, digit)[0]
+
     def segmented_copy(self, src, dst, elem_bytes, src_off, dst_off, length, nseg):
         s, t = src.numpy(), dst.numpy()
         for so, do, ln in zip(src_off.tolist(), dst_off.tolist(), length.tolist()):
@@ -100,7 +115,13 @@ def _worker(rank, world, port, tname, dist_name, sizes, outdir, schedule="per-pa
         x = torch.from_numpy(mine)
         sorter = ShardedRadixSort(backend=OracleBackend())
         {"per-pass": sorter.sort, "one": sorter.sort_one_exchange, "first": sorter.sort_exchange_first,
-         "pipelined": lambda *a, **k: sorter.sort_exchange_first(*a, chunks=3, **k)}[schedule](x, d, n_per_rank=list(sizes))
+         "pipelined": lambda *a, **k: sorter.sort_exchange_first(*a, chunks=3, **k),
+         "overlapped": lambda *a, **k: sorter.sort_exchange_first(*a, chunks=3, sub_ranges=3, **k),
+         "overlapped2": lambda *a, **k: sorter.sort_exchange_first(*a, chunks=1, sub_ranges=2, **k)}[schedule](x, d, n_per_rank=list(sizes))
+        if schedule == "overlapped":  # the donated form hands back another buffer
+            y = torch.from_numpy(mine.copy())
+            r = sorter.sort_exchange_first(y, d, n_per_rank=list(sizes), chunks=2, sub_ranges=4, donate=True)
+            assert np.array_equal(r.numpy(), x.numpy()), "donated result differs"
         np.save(os.path.join(outdir, f"out{rank}.npy"), x.numpy())
     finally:
         dist.destroy_process_group()
@@ -134,7 +155,7 @@ def test_sharded_gloo_matches_single_sort(orc, tmp_path, world, tname, dist_name
     (3, "(u8,u8)", "uniform", (900, 1100, 1000)),  # one-digit keys: the top digit is the whole key
     (3, "u32", "sorted", (2000, 1, 3000)),
 ])
-@pytest.mark.parametrize("schedule", ["one", "first", "pipelined"])
+@pytest.mark.parametrize("schedule", ["one", "first", "pipelined", "overlapped", "overlapped2"])
 def test_one_exchange_gloo_matches_single_sort(orc, tmp_path, world, tname, dist_name, sizes, schedule):
     import torch.multiprocessing as mp
     port = _free_port()
@@ -192,7 +213,8 @@ def _gpu_worker(rank, world, port, tname, dist_name, sizes, outdir, schedule="pe
         x = torch.from_numpy(full[off * d.elem_bytes:(off + sizes[rank]) * d.elem_bytes].copy()).cuda()
         sorter = ShardedRadixSort()  # product backend: HIP through the C-ABI
         {"per-pass": sorter.sort, "one": sorter.sort_one_exchange, "first": sorter.sort_exchange_first,
-         "pipelined": lambda *a, **k: sorter.sort_exchange_first(*a, chunks=4, **k)}[schedule](x, d, n_per_rank=list(sizes))
+         "pipelined": lambda *a, **k: sorter.sort_exchange_first(*a, chunks=4, **k),
+         "overlapped": lambda *a, **k: sorter.sort_exchange_first(*a, chunks=3, sub_ranges=4, **k)}[schedule](x, d, n_per_rank=list(sizes))
         np.save(os.path.join(outdir, f"out{rank}.npy"), x.cpu().numpy())
     finally:
         dist.destroy_process_group()
@@ -222,7 +244,7 @@ def test_sharded_hip_two_ranks_one_gpu(orc, tmp_path, tname, dist_name, sizes):
     ("(u32,u32)", "two", (200000, 123457)),
     ("i16", "equal", (65536, 70000)),
 ])
-@pytest.mark.parametrize("schedule", ["one", "first", "pipelined"])
+@pytest.mark.parametrize("schedule", ["one", "first", "pipelined", "overlapped"])
 def test_one_exchange_hip_two_ranks_one_gpu(orc, tmp_path, tname, dist_name, sizes, schedule):
     import torch.multiprocessing as mp
     port = _free_port()
@@ -231,6 +253,47 @@ def test_one_exchange_hip_two_ranks_one_gpu(orc, tmp_path, tname, dist_name, siz
     lay = orc.Layout(*util.TYPES[tname])
     full = util.make_input(tname, sum(sizes), dist_name, seed=78)
     assert np.array_equal(got, orc.sort_parallel(full, lay, 4))
+
+
+def _gpu_big_worker(rank, world, port, logn, schedule):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import radix_sort_amd as rs
+    from radix_sort_amd.sharded import ShardedRadixSort
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        d = rs.tuple_of("u64", 8)
+        n = 1 << logn
+        ctx = rs.default_context(0)
+        x = torch.empty(n * d.elem_bytes, dtype=torch.uint8, device="cuda")
+        # configs[4]'s slice: Zipf(1) u64 keys, payload = GLOBAL index (rank * n + i): reveals instability across ranks too
+        ctx.generate_device(x.data_ptr(), n, d, rs.GEN_ZIPF, 0x5EED0004, 1.0, rank * n, torch.cuda.current_stream().cuda_stream)
+        sorter = ShardedRadixSort()
+        before = sorter.checksum(x, d)
+        if schedule == "per-pass":
+            sorter.sort(x, d, [n] * world)
+        elif schedule == "overlapped":
+            x = sorter.sort_exchange_first(x, d, [n] * world, chunks=4, sub_ranges=4, donate=True)
+        else:
+            sorter.sort_exchange_first(x, d, [n] * world, chunks=4)
+        sorter.verify(x, d, before)  # the cross-rank check bench.py --gpus N runs
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("schedule", ["pipelined", "overlapped", "per-pass"])
+def test_torch_distributed_path_at_baseline_size(schedule):
+    """the torch.distributed path at a BASELINE size under pytest: 2 gloo ranks on the one GPU over
+    2 x 2^27 (u64,u64) Zipf pairs (configs[4]'s slice per GPU), payload = global index, through the exchange-first
+    schedule (4 ranges; 4 sub-ranges x 4 ranges) and the per-pass schedule (the north star's), checked by
+    ShardedRadixSort.verify: slices sorted and stable, multiset checksum all-reduced, rank-boundary keys in order."""
+    import torch.multiprocessing as mp
+    mp.spawn(_gpu_big_worker, args=(2, _free_port(), 27, schedule), nprocs=2, join=True)
 
 
 @pytest.mark.gpu

@@ -7,6 +7,6 @@ cd ${GRAFT_REPO_ROOT:-$(dirname $0)/..}
 R=${1:-2}; wl=${2:-c2-256m-u32}
 o=gpurun_out/rehearse; mkdir -p $o
 for ex in first one per-pass; do
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node $R --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus $R --steps 2 --warmup 1 --backend gloo --exchange $ex --workload $wl > $o/n${R}_$ex.log 2>&1
+  python bench.py --gpus $R --steps 2 --warmup 1 --backend gloo --exchange $ex --workload $wl > $o/n${R}_$ex.log 2>&1
   echo "== N=$R gloo --exchange $ex: rc $?"; grep -a '^{"metric"' $o/n${R}_$ex.log | cut -c1-300 || tail -5 $o/n${R}_$ex.log
 done
