@@ -108,10 +108,13 @@ enum {
                                   here under the real sweeps' LDS contention); a mismatch makes rsx_ctx_check fail */
     RSX_OPT_SMALL_SORT = 10,   /* 1 (default): arrays of at most one tile (14336 4-byte, 7168 8-byte, 2560 16-byte
                                   elements ...) are sorted by ONE launch of one workgroup; 0: by the general path */
-    RSX_OPT_MID_SORT = 11      /* 1 (default): middle-size arrays (up to 2^22 4-byte, 2^21 8-byte, 2^20 16-byte
-                                  elements) whose most significant digit spreads them over the 256 buckets are split
-                                  by that digit and every bucket is sorted in LDS by one workgroup (two trips through
-                                  memory instead of D); 0: LSD passes always */
+    RSX_OPT_MID_SORT = 11      /* middle-size arrays (up to 2^22 4-byte, 2^21 8-byte, 2^20 16-byte elements): when their most
+                                  significant digit spreads them over its 256 buckets, one sweep makes the buckets and one
+                                  workgroup per bucket sorts it in LDS (two trips through memory instead of D).  1 (default):
+                                  the host forecasts from what the context's previous middle-size sort reported; an input
+                                  that is skewed after all is still sorted correctly (an oversized bucket goes through
+                                  memory), then the context keeps to LSD passes for its next sorts.  0: LSD passes always,
+                                  top digit not even counted.  2: always split.  3: always LSD passes. */
 };
 int rsx_ctx_set_option(rsx_ctx *ctx, int option, uint64_t value);
 enum {

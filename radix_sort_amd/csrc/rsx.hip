@@ -168,13 +168,28 @@ int launch_totals(rsx_ctx* ctx, const RegionGeom& g, const unsigned long long* J
     return RSX_OK;
 }
 
-// zeroes what a sort (or a lone pass) accumulates into before its count kernel: every pass's tickets and
-// roll-call words and the used part of count matrix 0 -- one contiguous memset (the count kernel clears
-// matrix 1, the first sweep matrix 2)
-int zero_counters(rsx_ctx* ctx, const RegionGeom& g, hipStream_t st) {
-    RSX_HIP(hipMemsetAsync(ctx->aux + OFF_TICKETS, 0, OFF_J0 - OFF_TICKETS + (size_t)J_REPL * g.num_regions * RADIX * sizeof(uint64_t), st));
+// Picks the control block of the sort (or lone pass) being enqueued -- every pass's tickets and roll-call words, the
+// top digit's count matrix and count matrix 0, all zero -- and tells the count kernel which block to zero on its way:
+// the one the previous sort used (rsx_internal.hpp, aux layout).  A sort that is being captured into a graph uses
+// block 2 and zeroes it itself (a replay cannot alternate); so does the sort after a failed enqueue, for both blocks.
+int begin_control(rsx_ctx* ctx, hipStream_t st) {
+    ctx->clean16 = nullptr;
+    ctx->clean16_n = 0;
+    if (capturing(st)) {
+        ctx->cb = 2;
+        RSX_HIP(hipMemsetAsync(cb_of(ctx, 2), 0, CB_BYTES, st));
+        return RSX_OK;
+    }
+    if (ctx->cb_dirty) RSX_HIP(hipMemsetAsync(cb_of(ctx, 0), 0, 2 * CB_BYTES, st));
+    const uint32_t prev = ctx->cb_alt;
+    ctx->cb_alt ^= 1u;
+    ctx->cb = ctx->cb_alt;
+    ctx->clean16 = reinterpret_cast<uint4*>(cb_of(ctx, prev));
+    ctx->clean16_n = CB_BYTES / 16;
+    ctx->cb_dirty = true;  // until the enqueue has gone through (end_control)
     return RSX_OK;
 }
+inline void end_control(rsx_ctx* ctx) { ctx->cb_dirty = false; }
 
 int check_common(rsx_ctx* ctx, const rsx_layout* L) {
     if (!ctx) return RSX_ERR_ARG;
@@ -216,13 +231,30 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
     // at most one tile: all D passes in one launch of one workgroup (rsx_small_kernel.hpp)
     if (!counting_path && n <= (size_t)512 * kpt_for((int)L->elem_bytes) && !(ctx->options & OPT_NO_SMALL_SORT))  // one 512-thread tile
         return small_dispatch(ctx, d_data, n, L, st);
-    // Middle sizes (more than one tile, up to mid_max_elems): the count kernel also counts the MOST significant digit
-    // and the first sweep decides from those counts whether it is the bucket split (then rsx_bucket_sort_kernel
-    // finishes the sort and the sweeps behind it return at once) or the first LSD pass of the general path.
+    // Middle sizes (more than one tile, up to mid_max_elems): the count kernel also counts the MOST significant digit.
+    // If that digit spreads the array over its 256 buckets so that each fits a workgroup's LDS, one sweep makes the
+    // buckets and rsx_bucket_sort_kernel sorts each by the remaining digits: 4 launches and two trips through memory
+    // instead of D + 2 and D.  Whether it does is known on the device only, and a launch costs ~4 us even when it
+    // returns at once, so the host FORECASTS from what the previous middle-size sort reported (a host-visible word,
+    // read without synchronising: it may lag, and either way the result is right -- a bucket that does not fit after
+    // all is sorted through memory by its one workgroup, slowly, after which the context keeps to LSD passes for a while).
     const bool mid = !counting_path && D >= 2 && (uint64_t)n <= mid_max_for(L->elem_bytes) && geom.num_regions <= MID_MAX_REGIONS &&
                      status32(geom) && !(ctx->options & OPT_NO_MID_SORT);
+    uint32_t mid_mode = 0;
+    if (mid) {
+        const uint32_t hint = reinterpret_cast<volatile uint32_t*>(ctx->host_err)[8];  // 0 nothing yet, 1 fits, 2 does not
+        if (ctx->mid_choice == 1 && hint == 2 && ctx->mid_cooldown == 0) ctx->mid_cooldown = 8;  // a split met a skewed input
+        if (ctx->mid_cooldown > 0) {
+            --ctx->mid_cooldown;
+            mid_mode = 2;
+        } else {
+            mid_mode = hint == 2 ? 2u : 1u;
+        }
+        if (ctx->mid_force) mid_mode = ctx->mid_force;
+        ctx->mid_choice = mid_mode;
+    }
     // count phase of pass 0 (mod.rs:90-109); later passes are counted by the sweep before them
-    rc = zero_counters(ctx, geom, st);
+    rc = begin_control(ctx, st);
     if (rc) return rc;
     if (mid) rc = hist2_dispatch(ctx, d_data, geom, L, 0, J_of(ctx, 0), D - 1, JT_of(ctx), J_of(ctx, 1), st);
     else rc = hist_dispatch(ctx, d_data, geom, L, 0, J_of(ctx, 0), D > 1 ? J_of(ctx, 1) : nullptr, !counting_path, st);
@@ -238,10 +270,12 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
                            (uint64_t)n, J_of(ctx, 0), geom.num_regions, status32(geom) ? 1u : 0u,
                            L->key_kind == RSX_KEY_SIGNED ? 0x80u : 0u);
         RSX_HIP(hipGetLastError());
+        end_control(ctx);
         return RSX_OK;
     }
     // pass loop with ping-pong (mod.rs:84-89); the prefix phase (mod.rs:110-120) is the prologue of each sweep
     ctx->last_sort_passes = D;
+    ctx->cb_last = ctx->cb;
     for (uint32_t d = 0; d < D; ++d) {
         const void* src = (d % 2 == 0) ? d_data : d_tmp;
         void* dst = (d % 2 == 0) ? d_tmp : d_data;
@@ -250,21 +284,22 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
         const int xf = (d == 0 ? 1 : 0) | (d + 1 == D ? 2 : 0);  // key map on at the first, off at the last pass
         ctx->pass_index = d;
         ctx->pass_last = d + 1 == D;
-        ctx->pass_mid = mid ? (d == 0 ? 1u : 2u) : 0u;
-        // (middle sizes: the passes behind the first return at once when it made the buckets -- ~4 us per launch all
-        // the same; putting them on a side stream beside the bucket kernel cost more in event hand-offs than it hid:
-        // 2^16 u32 60 -> 75 us)
+        ctx->pass_mid = d == 0 ? mid_mode : 0u;
         rc = sweep_dispatch(ctx, src, dst, geom, L, d, J_of(ctx, d % 3), jnext, jzero, xf, st);  // mod.rs:121-168
         ctx->pass_mid = 0;
         if (rc) return rc;
-        if (mid && d == 0) {  // the buckets were made in d_tmp; sorted, they land in d_data
+        if (mid_mode == 1) {  // the buckets were made in d_tmp; sorted, they land in d_data
             rc = bucket_dispatch(ctx, d_tmp, d_data, geom, L, st);
             if (rc) return rc;
+            ctx->last_sort_passes = 1;
+            end_control(ctx);
+            return RSX_OK;
         }
     }
 
     if (D % 2 == 1)  // odd-D copy-back (mod.rs:170-174)
         RSX_HIP(hipMemcpyAsync(d_data, d_tmp, n * (size_t)L->elem_bytes, hipMemcpyDeviceToDevice, st));
+    end_control(ctx);
     return RSX_OK;
 }
 
@@ -435,8 +470,9 @@ int rsx_ctx_set_option(rsx_ctx* ctx, int option, uint64_t value) try {
             flag(OPT_NO_SMALL_SORT, value == 0);
             return RSX_OK;
         case RSX_OPT_MID_SORT:
-            if (value > 1) return fail(ctx, RSX_ERR_ARG, "RSX_OPT_MID_SORT: 0 or 1");
+            if (value > 3) return fail(ctx, RSX_ERR_ARG, "RSX_OPT_MID_SORT: 0 (off), 1 (forecast), 2 (always split) or 3 (always LSD passes)");
             flag(OPT_NO_MID_SORT, value == 0);
+            ctx->mid_force = value >= 2 ? (uint32_t)value - 1u : 0u;
             return RSX_OK;
         default:
             return fail(ctx, RSX_ERR_ARG, "unknown option");
@@ -465,7 +501,8 @@ int rsx_ctx_get_info(rsx_ctx* ctx, int what, uint64_t* out) try {
             uint64_t stat = 0, placed = 0;
             for (uint32_t p = 0; p < ctx->last_sort_passes && p < (uint32_t)MAX_PASSES; ++p) {
                 uint32_t mode = 0;  // the roll call's verdict word: 1 static, 3 static + placement verified, 2 / 0 tickets
-                RSX_HIP(hipMemcpy(&mode, tickets_of(ctx, p) + ROLL_MODE, sizeof mode, hipMemcpyDeviceToHost));
+                RSX_HIP(hipMemcpy(&mode, reinterpret_cast<uint32_t*>(cb_of(ctx, ctx->cb_last) + CB_TICKETS) + (size_t)p * TICKET_WORDS + ROLL_MODE,
+                                  sizeof mode, hipMemcpyDeviceToHost));
                 stat += (mode == 1u || mode == 3u) ? 1u : 0u;
                 placed += mode == 3u ? 1u : 0u;
             }
@@ -685,11 +722,13 @@ int rsx_histogram_device(rsx_ctx* ctx, const void* d_src, size_t n, const rsx_la
     if (rc) return rc;
     Enqueue enq(ctx, st);
     const RegionGeom geom = make_geom(ctx, n, L->elem_bytes);
-    rc = zero_counters(ctx, geom, st);
+    rc = begin_control(ctx, st);
     if (rc) return rc;
     rc = hist_dispatch(ctx, d_src, geom, L, digit, J_of(ctx, 0), nullptr, false, st);
     if (rc) return rc;
-    return launch_totals(ctx, geom, J_of(ctx, 0), d_hist, st);  // column sums -> d_hist
+    rc = launch_totals(ctx, geom, J_of(ctx, 0), d_hist, st);  // column sums -> d_hist
+    if (rc == RSX_OK) end_control(ctx);
+    return rc;
 } catch (...) {
     return RSX_ERR_HIP;
 }
@@ -703,7 +742,7 @@ int partition_locked(rsx_ctx* ctx, const void* d_src, void* d_dst, size_t n, con
     if (rc) return rc;
     Enqueue enq(ctx, st);
     const RegionGeom geom = make_geom(ctx, n, L->elem_bytes);
-    rc = zero_counters(ctx, geom, st);
+    rc = begin_control(ctx, st);
     if (rc) return rc;
     rc = hist_dispatch(ctx, d_src, geom, L, digit, J_of(ctx, 0), nullptr, true, st);
     if (rc) return rc;
@@ -713,7 +752,9 @@ int partition_locked(rsx_ctx* ctx, const void* d_src, void* d_dst, size_t n, con
     }
     ctx->pass_index = 0;
     ctx->pass_last = true;
-    return sweep_dispatch(ctx, d_src, d_dst, geom, L, digit, J_of(ctx, 0), nullptr, nullptr, 3, st);  // a lone pass maps and unmaps
+    rc = sweep_dispatch(ctx, d_src, d_dst, geom, L, digit, J_of(ctx, 0), nullptr, nullptr, 3, st);  // a lone pass maps and unmaps
+    if (rc == RSX_OK) end_control(ctx);
+    return rc;
 }
 }  // namespace
 
@@ -798,14 +839,17 @@ int rsx_partition_scatter_device(rsx_ctx* ctx, const void* d_src, void* d_dst, s
     Enqueue enq(ctx, st);
     const RegionGeom geom = make_geom(ctx, nk, L->elem_bytes);
     // what the count kernel of a whole sort clears on its way: this pass's control words and status words
-    RSX_HIP(hipMemsetAsync(tickets_of(ctx, 0), 0, TICKET_WORDS * sizeof(uint32_t), st));
+    RSX_HIP(hipMemsetAsync(part_tickets_of(ctx), 0, TICKET_WORDS * sizeof(uint32_t), st));
     RSX_HIP(hipMemsetAsync(ctx->status, 0, status_bytes_for(ctx, nk, L->elem_bytes), st));
     ctx->pass_index = 0;
     ctx->pass_last = true;
     ctx->pass_mid = 0;
+    ctx->tickets_override = part_tickets_of(ctx);  // outside the alternating control blocks
     const size_t off = beg * (size_t)L->elem_bytes;
-    return sweep_dispatch(ctx, static_cast<const char*>(d_src) + off, static_cast<char*>(d_dst) + off, geom, L, digit,
-                          ctx->part_J + (size_t)k * (J_BYTES / sizeof(unsigned long long)), nullptr, nullptr, 3, st);
+    rc = sweep_dispatch(ctx, static_cast<const char*>(d_src) + off, static_cast<char*>(d_dst) + off, geom, L, digit,
+                        ctx->part_J + (size_t)k * (J_BYTES / sizeof(unsigned long long)), nullptr, nullptr, 3, st);
+    ctx->tickets_override = nullptr;
+    return rc;
 } catch (...) {
     return RSX_ERR_HIP;
 }

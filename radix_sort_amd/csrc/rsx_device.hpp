@@ -277,6 +277,7 @@ __global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restric
                                                        unsigned long long* __restrict__ J,
                                                        unsigned long long* __restrict__ jclear, uint32_t j32,
                                                        uint4* __restrict__ zero16, uint64_t zero16_n,
+                                                       uint4* __restrict__ zero16b, uint64_t zero16b_n,
                                                        DigitSpec spec2 = DigitSpec{}, unsigned long long* __restrict__ J2 = nullptr) {
     __shared__ uint32_t lh[TWO ? 2 * RADIX : RADIX];
     const uint32_t tid = threadIdx.x;
@@ -288,6 +289,9 @@ __global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restric
     // ... and so are the tile status words of the first sweep (a memset launch less per sort)
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + tid; i < zero16_n; i += (uint64_t)gridDim.x * blockDim.x)
         zero16[i] = make_uint4(0, 0, 0, 0);
+    // ... and the control block the PREVIOUS sort on this context used (the next one will find it clean: no memset launch)
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + tid; i < zero16b_n; i += (uint64_t)gridDim.x * blockDim.x)
+        zero16b[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const uint32_t r = blockIdx.x / blocks_per_region;
     const uint32_t sub = blockIdx.x % blocks_per_region;
@@ -407,13 +411,16 @@ struct SweepArgs {
     DigitSpec next;               // next pass's digit (when jnext != null)
     KeyXform xf;                  // signed/float key map applied on load (XF & 1) / undone on store (XF & 2)
     uint32_t opts;                // alternative paths, all bit-exact: SWEEP_OPT_*
-    // middle-size path (MID instantiation: the sort's first sweep): this launch is EITHER the bucket split by the
-    // most significant digit (then rsx_bucket_sort_kernel finishes the sort) OR the first LSD pass, decided here
-    // from the top digit's counts; `mid_flag` tells the kernels behind which (1 = buckets, 2 = LSD)
+    // middle-size path (MID instantiation: the sort's first sweep).  The host has decided, from what the previous
+    // middle-size sort of the context reported, whether this launch is the bucket split by the most significant digit
+    // (mid_mode 1: rsx_bucket_sort_kernel then finishes the sort) or the first LSD pass (mid_mode 2).  Either way it
+    // reports through `mid_hint` (host-visible) whether every bucket of THIS input would fit a workgroup of the bucket
+    // kernel (1) or not (2): the host's forecast for the next sort.
     const unsigned long long* mid_J;  // count matrix of the most significant digit
     DigitSpec mid_spec;           // the most significant digit (of the mapped key)
-    uint32_t mid_cap;             // largest bucket rsx_bucket_sort_kernel takes
-    uint32_t* mid_flag;           // MID: written; other sweeps of the sort: read (1 = nothing left to do), or null
+    uint32_t mid_cap;             // largest bucket rsx_bucket_sort_kernel sorts in LDS
+    uint32_t mid_mode;
+    uint32_t* mid_hint;
     uint32_t dbg;                 // RSX_TUNING builds: timing-only ablation switches (0 in production)
     unsigned long long* dbg_cnt;  // [8] diagnostic counters (RSX_TUNING, dbg & 0x100)
 };
@@ -614,12 +621,6 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
     uint32_t* s_misc = s_jn + (NEXT ? a.g.num_regions * RADIX : 0);                    // [32]
     static_assert(NWAVE * RADIX * sizeof(Cnt) >= RADIX * sizeof(uint64_t), "s_base must fit in s_whist");
 
-    if constexpr (!MID) {
-        // middle-size sorts: the first sweep decided that rsx_bucket_sort_kernel finishes the sort -- nothing to do here
-        if (a.mid_flag != nullptr &&
-            __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.mid_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 1)
-            return;
-    }
     const E* __restrict__ src = static_cast<const E*>(a.src);
     S* status = static_cast<S*>(a.status);
     const uint32_t NR = a.g.num_regions;
@@ -746,10 +747,9 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
     };
     uint64_t tot_home, below_home;
     if constexpr (MID) {
-        // Middle-size sort, first sweep.  If no bucket of the MOST significant digit exceeds what one workgroup sorts
-        // in LDS (a.mid_cap), this launch splits the array into those 256 buckets and rsx_bucket_sort_kernel sorts
-        // each by the remaining digits (two trips through memory instead of D); else it is the ordinary first LSD
-        // pass.  Every workgroup takes the same decision from the same counts; workgroup 0 records it.
+        // Middle-size sort, first sweep: the bucket split by the MOST significant digit (a.mid_mode == 1:
+        // rsx_bucket_sort_kernel then sorts every bucket by the remaining digits -- two trips through memory instead
+        // of D) or the ordinary first LSD pass (2).  The largest bucket of the top digit is reported to the host.
         load_counts(a.mid_J, home, tot_home, below_home);
         const uint32_t t = threadIdx.x;
         if (WG >= 2 * RADIX && t >= RADIX && t < 2 * RADIX) s_half[t - RADIX] = tot_home;
@@ -766,7 +766,8 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         uint64_t big = s_scan[0];
 #pragma unroll
         for (int w = 1; w < RADIX / WAVE; ++w) big = s_scan[w] > big ? s_scan[w] : big;
-        msd = __builtin_amdgcn_readfirstlane((int)(big <= (uint64_t)a.mid_cap)) != 0;
+        const bool fits = __builtin_amdgcn_readfirstlane((int)(big <= (uint64_t)a.mid_cap)) != 0;
+        msd = a.mid_mode == 1u;
         __syncthreads();  // s_half / s_scan are used again by scan_cursors
         if (msd) {
             spec = a.mid_spec;
@@ -774,7 +775,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         } else {
             load_counts(a.J, home, tot_home, below_home);
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0) *a.mid_flag = msd ? 1u : 2u;
+        if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.mid_hint, fits ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     } else {
         load_counts(a.J, home, tot_home, below_home);
     }

@@ -23,27 +23,30 @@
 namespace rsxh {
 using namespace rsx;
 
-// aux block layout (one hipMalloc, zeroed at creation).  A sort zeroes, with ONE memset before its
-// count kernel, every pass's ticket / roll-call words and the part of count matrix 0 it uses; the
-// count kernel clears matrix 1, the first sweep matrix 2 (and so on round the three).
+// aux block layout (one hipMalloc, zeroed at creation).
+// What a sort ACCUMULATES into before any of its kernels could clear it -- every pass's ticket / roll-call words, the
+// count matrix of the most significant digit (middle sizes) and count matrix 0 -- lives in a CONTROL BLOCK, and there
+// are three of them: sort k uses block k % 2 and its count kernel, on its way, zeroes the block sort k - 1 used, so
+// that no memset launch stands between two sorts (3.5 us of 60 at 2^16 keys).  Block 2 belongs to sorts that are being
+// captured into a graph: a replay cannot alternate, so those zero their block themselves, with a memset, as every
+// sort did before.  Count matrices 1 and 2 are cleared by the kernels of the sort itself (count kernel, first sweep).
 // A count matrix is kept in J_REPL replicas (rsx_device.hpp): [J_REPL][num_regions][256] u64.
 constexpr int MAX_PASSES = 16;                                                   // u128 keys
 constexpr size_t J_BYTES = (size_t)J_REPL * MAX_REGIONS * RADIX * sizeof(uint64_t);  // one count matrix, all replicas
 constexpr size_t TICKET_WORDS = ROLL_SHARDS + (size_t)ROLL_SHARD_COUNT * ROLL_SHARD_STRIDE;  // per pass (rsx_device.hpp)
-constexpr size_t OFF_TICKETS = 0;                                                // [MAX_PASSES][TICKET_WORDS] u32
-// middle-size sorts: count matrix of the MOST significant digit (at most MID_MAX_REGIONS regions), between the control
-// words and count matrix 0 so that the one memset of a sort clears it too
 constexpr uint32_t PART_MAX_SUB = 16;  // sub-ranges of rsx_partition_count_device / rsx_partition_scatter_device
-constexpr uint32_t MID_MAX_REGIONS = 8;
-constexpr size_t OFF_JT = ((MAX_PASSES * TICKET_WORDS * 4 + 255) / 256) * 256;
+constexpr uint32_t MID_MAX_REGIONS = 8;  // middle-size sorts: regions of the most significant digit's count matrix
+constexpr size_t CB_TICKETS = 0;                                                 // [MAX_PASSES][TICKET_WORDS] u32
+constexpr size_t CB_JT = ((MAX_PASSES * TICKET_WORDS * 4 + 255) / 256) * 256;    // count matrix of the most significant digit
 constexpr size_t JT_BYTES = (size_t)J_REPL * MID_MAX_REGIONS * RADIX * sizeof(uint64_t);
-constexpr size_t OFF_J0 = OFF_JT + JT_BYTES;
-// word of pass 0's control block that tells the kernels behind the first sweep of a middle-size sort what it decided
-constexpr uint32_t MID_FLAG_WORD = MAX_REGIONS + 2;
-static_assert(MID_FLAG_WORD < (uint32_t)ROLL_SHARDS, "control words of a pass");
-constexpr size_t OFF_J1 = OFF_J0 + J_BYTES;
+constexpr size_t CB_J0 = CB_JT + JT_BYTES;                                       // count matrix 0
+constexpr size_t CB_BYTES = CB_J0 + J_BYTES;
+static_assert(CB_BYTES % 16 == 0, "control blocks are zeroed with 16-byte stores");
+constexpr int CB_COUNT = 3;
+constexpr size_t OFF_J1 = CB_COUNT * CB_BYTES;
 constexpr size_t OFF_J2 = OFF_J1 + J_BYTES;
-constexpr size_t OFF_BASE = OFF_J2 + J_BYTES;                                    // scratch of the context self-tests
+constexpr size_t OFF_PART_TICKETS = OFF_J2 + J_BYTES;                            // control words of rsx_partition_scatter_device
+constexpr size_t OFF_BASE = OFF_PART_TICKETS + ((TICKET_WORDS * 4 + 255) / 256) * 256;  // scratch of the context self-tests
 constexpr size_t OFF_FLAGS = OFF_BASE + 4096;                                    // self-test verdicts
 constexpr size_t OFF_DBG = OFF_FLAGS + 256;                                      // 16 waves x 8 diagnostic counters
 constexpr size_t AUX_BYTES = OFF_DBG + 1024;
@@ -91,7 +94,17 @@ struct rsx_ctx {
     uint32_t pass_index = 0;   // of the sweep being launched within its sort (selects the status half, J rotation)
     bool pass_last = true;     // no pass follows: nothing to clean
     uint32_t last_sort_passes = 0;  // sweep passes of the last sort (RSX_INFO_LAST_PASSES)
-    uint32_t pass_mid = 0;     // middle-size sort: 1 = the sweep being launched decides (MID instantiation), 2 = it reads the decision
+    uint4* clean16 = nullptr;  // what the next count kernel zeroes on its way (the previous sort's control block)
+    uint64_t clean16_n = 0;
+    uint32_t cb_alt = 0;       // which of the two alternating blocks the last uncaptured sort used
+    uint32_t* tickets_override = nullptr;  // rsx_partition_scatter_device: control words outside the blocks
+    uint32_t cb = 0;           // control block of the sort being enqueued (aux layout above)
+    uint32_t cb_last = 0;      // ... of the last sort that ran sweeps (RSX_INFO_LAST_PASSES)
+    bool cb_dirty = false;     // an enqueue failed half way: both alternating blocks are zeroed by memset before the next sort
+    uint32_t pass_mid = 0;     // middle-size sort, first sweep (MID instantiation): 1 = bucket split by the top digit, 2 = first LSD pass
+    uint32_t mid_choice = 0;   // what the last middle-size sort was enqueued as (1 / 2)
+    uint32_t mid_force = 0;    // RSX_OPT_MID_SORT 2 / 3: always split (1) / always LSD passes (2)
+    uint32_t mid_cooldown = 0; // sorts to go by LSD passes after a bucket split met a skewed input
     bool rank_atomic = false;  // LDS atomic ordering self-test passed (set when the workspace is first made)
     bool l2_local = false;     // same-XCD hand-off self-test passed: chains may keep status words in their L2
     uint32_t hot_lanes = 16;
@@ -254,16 +267,17 @@ inline DigitSpec make_spec(const rsx_layout* L, uint32_t digit) {
 
 // the three count matrices rotate: pass d reads J_of(d % 3), accumulates the next pass's into
 // J_of((d + 1) % 3) and zeroes J_of((d + 2) % 3) for the pass after
+inline char* cb_of(rsx_ctx* c, uint32_t which) { return c->aux + (size_t)which * CB_BYTES; }
 inline unsigned long long* J_of(rsx_ctx* c, uint32_t which) {
-    const size_t off = which == 0 ? OFF_J0 : which == 1 ? OFF_J1 : OFF_J2;
-    return reinterpret_cast<unsigned long long*>(c->aux + off);
+    char* p = which == 0 ? cb_of(c, c->cb) + CB_J0 : which == 1 ? c->aux + OFF_J1 : c->aux + OFF_J2;
+    return reinterpret_cast<unsigned long long*>(p);
 }
-inline unsigned long long* JT_of(rsx_ctx* c) { return reinterpret_cast<unsigned long long*>(c->aux + OFF_JT); }
-inline uint32_t* mid_flag_of(rsx_ctx* c) { return reinterpret_cast<uint32_t*>(c->aux + OFF_TICKETS) + MID_FLAG_WORD; }
+inline unsigned long long* JT_of(rsx_ctx* c) { return reinterpret_cast<unsigned long long*>(cb_of(c, c->cb) + CB_JT); }
 inline uint64_t* base_of(rsx_ctx* c) { return reinterpret_cast<uint64_t*>(c->aux + OFF_BASE); }
 inline uint32_t* tickets_of(rsx_ctx* c, uint32_t pass) {
-    return reinterpret_cast<uint32_t*>(c->aux + OFF_TICKETS) + (size_t)pass * TICKET_WORDS;
+    return reinterpret_cast<uint32_t*>(cb_of(c, c->cb) + CB_TICKETS) + (size_t)pass * TICKET_WORDS;
 }
+inline uint32_t* part_tickets_of(rsx_ctx* c) { return reinterpret_cast<uint32_t*>(c->aux + OFF_PART_TICKETS); }
 inline uint32_t* flags_of(rsx_ctx* c) { return reinterpret_cast<uint32_t*>(c->aux + OFF_FLAGS); }
 
 // ---- per-element-size launchers (defined in rsx_launch_impl.hpp, instantiated in rsx_es.hip) ----

@@ -24,8 +24,10 @@ int launch_hist_t(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_
     LaunchTimer lt(ctx, RSX_PROF_HIST, st);
     hipLaunchKernelGGL((rsx_hist_kernel<ES, FLT>), dim3((uint32_t)(bpr * g.num_regions)), dim3(512), 0, st,
                        static_cast<const Elem<ES>*>(src), g, make_spec(L, digit), (uint32_t)bpr, J, jclear, status32(g) ? 1u : 0u,
-                       static_cast<uint4*>(ctx->status), zero16_n);
+                       static_cast<uint4*>(ctx->status), zero16_n, ctx->clean16, ctx->clean16_n);
     RSX_HIP(hipGetLastError());
+    ctx->clean16 = nullptr;  // done once per sort
+    ctx->clean16_n = 0;
     return RSX_OK;
 }
 template <int ES>
@@ -50,12 +52,14 @@ int launch_hist2(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_l
     if (L->key_kind != RSX_KEY_UNSIGNED)
         hipLaunchKernelGGL((rsx_hist_kernel<ES, true, true>), dim3((uint32_t)(bpr * g.num_regions)), dim3(512), 0, st,
                            static_cast<const Elem<ES>*>(src), g, make_spec(L, digit), (uint32_t)bpr, J, jclear, status32(g) ? 1u : 0u,
-                           static_cast<uint4*>(ctx->status), zero16_n, make_spec(L, digit2), J2);
+                           static_cast<uint4*>(ctx->status), zero16_n, ctx->clean16, ctx->clean16_n, make_spec(L, digit2), J2);
     else
         hipLaunchKernelGGL((rsx_hist_kernel<ES, false, true>), dim3((uint32_t)(bpr * g.num_regions)), dim3(512), 0, st,
                            static_cast<const Elem<ES>*>(src), g, make_spec(L, digit), (uint32_t)bpr, J, jclear, status32(g) ? 1u : 0u,
-                           static_cast<uint4*>(ctx->status), zero16_n, make_spec(L, digit2), J2);
+                           static_cast<uint4*>(ctx->status), zero16_n, ctx->clean16, ctx->clean16_n, make_spec(L, digit2), J2);
     RSX_HIP(hipGetLastError());
+    ctx->clean16 = nullptr;
+    ctx->clean16_n = 0;
     return RSX_OK;
 }
 
@@ -100,7 +104,7 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
     a.g = g;
     a.J = J;
     a.status = half[which];
-    a.tickets = tickets_of(ctx, ctx->pass_index);
+    a.tickets = ctx->tickets_override ? ctx->tickets_override : tickets_of(ctx, ctx->pass_index);
     a.prev_mode = ctx->pass_index ? tickets_of(ctx, ctx->pass_index - 1) + ROLL_SHARDS + 1 : nullptr;
     a.jnext = jnext;
     a.jzero = jzero;
@@ -119,7 +123,8 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
     a.mid_J = nullptr;
     a.mid_spec = a.spec;
     a.mid_cap = 0;
-    a.mid_flag = ctx->pass_mid ? mid_flag_of(ctx) : nullptr;
+    a.mid_mode = ctx->pass_mid;
+    a.mid_hint = ctx->host_err_dev + 8;  // second word group of the host-visible block
     if constexpr (MID) {
         a.mid_J = JT_of(ctx);
         a.mid_spec = make_spec(L, L->key_bytes - 1);
@@ -200,7 +205,7 @@ int launch_sweep_n(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
                    hipStream_t st) {
     if constexpr ((XF & 2) == 0) {  // a pass that maps the keys back is a last pass: nothing to count for
         if constexpr (sizeof(S) == 4 && ES != 1) {  // the first sweep of a middle-size sort (regions of <= 2^30 elements by far)
-            if (jnext && ctx->pass_mid == 1) return launch_sweep_t<ES, S, XF, true, true>(ctx, src, dst, g, L, digit, J, jnext, jzero, st);
+            if (jnext && ctx->pass_mid != 0) return launch_sweep_t<ES, S, XF, true, true>(ctx, src, dst, g, L, digit, J, jnext, jzero, st);
         }
         if (jnext) return launch_sweep_t<ES, S, XF, true>(ctx, src, dst, g, L, digit, J, jnext, jzero, st);
     } else if (jnext) {
@@ -279,9 +284,7 @@ int launch_bucket_sort(rsx_ctx* ctx, const void* src, void* dst, const RegionGeo
         a.top_J = JT_of(ctx);
         a.num_regions = g.num_regions;
         a.j32 = status32(g) ? 1u : 0u;
-        a.mid_flag = mid_flag_of(ctx);
-        a.error = ctx->host_err_dev;
-        const size_t lds = (size_t)1024 * KPT * ES + 16 * RADIX * sizeof(uint32_t) + 64;
+        const size_t lds = (size_t)1024 * KPT * ES + 16 * RADIX * sizeof(uint32_t) + 64 + 3 * RADIX * sizeof(uint32_t);
         auto kern = rsx_bucket_sort_kernel<ES, KPT>;
         static thread_local bool attr_set = false;
         if (!attr_set) {  // more than 64 KiB of dynamic LDS has to be asked for

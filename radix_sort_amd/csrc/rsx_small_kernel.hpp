@@ -33,8 +33,6 @@ struct SmallArgs {
     const unsigned long long* top_J;  // count matrix of the top digit, [J_REPL][num_regions][256]
     uint32_t num_regions;
     uint32_t j32;                     // its entries are 32 bit
-    const uint32_t* mid_flag;         // 1: the first sweep made the buckets; anything else: nothing to do here
-    uint32_t* error;                  // host-visible error word (a bucket larger than the workgroup takes: cannot happen)
 };
 
 // Sorts elements [0, n) of `src` by `a.passes` digits into `dst` (same index range), n <= WG * KPT.
@@ -127,6 +125,122 @@ __device__ __forceinline__ void local_sort(const SmallArgs& a, const Elem<ES>* _
     }
 }
 
+// A bucket LARGER than a workgroup holds (the host predicted a spread-out top digit from the previous sort's counts and
+// this input is skewed): the workgroup sorts it through memory -- D-1 LSD passes (an odd number: the last lands in
+// `buf1`) between the bucket's ranges of the two buffers, each pass a count, a scan and a scatter of mod.rs:90-168 with
+// chunk == WG * KPT elements taken in order (stable ranks inside the chunk as in local_sort, running cursors across
+// chunks).  Slow (one CU for the whole bucket) and rare: the context falls back to LSD passes for its next sorts.
+template <int ES, int KPT, int WG>
+__device__ void big_bucket_sort(const SmallArgs& a, Elem<ES>* buf0, Elem<ES>* buf1, const uint32_t m, unsigned char* smem) {
+    constexpr int NWAVE = WG / WAVE;
+    constexpr uint32_t CH = (uint32_t)WG * KPT;
+    using E = Elem<ES>;
+    E* s_elems = reinterpret_cast<E*>(smem);
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem + (size_t)WG * KPT * sizeof(E));
+    uint32_t* s_misc = s_cnt + NWAVE * RADIX;  // [NWAVE]
+    uint32_t* s_gbase = s_misc + NWAVE;        // [256] where the next element of each digit goes, relative to the bucket
+    uint32_t* s_dstart = s_gbase + RADIX;      // [256] start of each digit's run in the sorted chunk
+    uint32_t* s_dcount = s_dstart + RADIX;     // [256] its length
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t* my = s_cnt + wave * RADIX;
+    E* src = buf0;
+    E* dst = buf1;
+    for (uint32_t pass = 0; pass < a.passes; ++pass) {
+        const DigitSpec spec = a.spec[pass];
+        const bool last = pass + 1 == a.passes;
+        if (tid < RADIX) s_gbase[tid] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < m; i += WG) atomicAdd(&s_gbase[elem_digit<ES, false>(src[i], spec)], 1u);  // count (mod.rs:90-109)
+        __syncthreads();
+        if (tid < RADIX) {  // prefix (mod.rs:110-120)
+            const uint32_t c = s_gbase[tid];
+            const uint32_t incl = wave_incl_scan<true>(c);
+            if (lane == 63) s_misc[wave] = incl;
+            s_dcount[tid] = incl - c;
+        }
+        __syncthreads();
+        if (tid < RADIX) {
+            uint32_t b = s_dcount[tid];
+            for (uint32_t w = 0; w < wave; ++w) b += s_misc[w];
+            s_gbase[tid] = b;
+        }
+        __syncthreads();
+        for (uint32_t c0 = 0; c0 < m; c0 += CH) {  // scatter (mod.rs:121-168), chunk by chunk in order
+            const uint32_t n = m - c0 < CH ? m - c0 : CH;
+            const uint32_t kp = (n + WG - 1) / WG;
+            const uint32_t seg = wave * (WAVE * kp) + lane;
+            E e[KPT];
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                e[j] = E{};
+                if ((uint32_t)j < kp) {
+                    const uint32_t p = seg + (uint32_t)j * WAVE;
+                    if (p < n) e[j] = src[c0 + p];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < RADIX / WAVE; ++i) my[i * WAVE + lane] = 0;
+            auto digit_of = [&](int j) -> uint32_t {
+                return (seg + (uint32_t)j * WAVE >= n) ? 255u : elem_digit<ES, false>(e[j], spec);
+            };
+            uint32_t rk[KPT];
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                rk[j] = 0;
+                if ((uint32_t)j < kp) {
+                    const uint32_t d = digit_of(j);
+                    const uint64_t mm = match_digit(d);  // (ballots: the rare path does not depend on the LDS ordering self-test)
+                    const uint32_t below = mbcnt64(mm);
+                    const uint32_t seen = my[d];
+                    if (below == 0) atomicAdd(&my[d], (uint32_t)__popcll(mm));
+                    rk[j] = seen + below;
+                }
+            }
+            __syncthreads();
+            uint32_t tcount = 0, incl = 0;
+            if (tid < RADIX) {
+#pragma unroll
+                for (int w = 0; w < NWAVE; ++w) tcount += s_cnt[w * RADIX + tid];
+                incl = wave_incl_scan<true>(tcount);
+                if (lane == 63) s_misc[wave] = incl;
+            }
+            __syncthreads();
+            if (tid < RADIX) {
+                uint32_t run = incl - tcount;
+                for (uint32_t w = 0; w < wave; ++w) run += s_misc[w];
+                s_dstart[tid] = run;
+                s_dcount[tid] = tid == RADIX - 1 ? tcount - (kp * WG - n) : tcount;  // padding slots rank as digit 255, last
+#pragma unroll
+                for (int w = 0; w < NWAVE; ++w) {
+                    const uint32_t c = s_cnt[w * RADIX + tid];
+                    s_cnt[w * RADIX + tid] = run;
+                    run += c;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < KPT; ++j)
+                if ((uint32_t)j < kp) s_elems[my[digit_of(j)] + rk[j]] = e[j];
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += WG) {
+                E x = s_elems[i];
+                const uint32_t d = elem_digit<ES, false>(x, spec);
+                const uint32_t pos = s_gbase[d] + (i - s_dstart[d]);
+                if (last && a.map_store) key_map<ES, true>(x, a.xf);
+                dst[pos] = x;
+            }
+            __syncthreads();
+            if (tid < RADIX) s_gbase[tid] += s_dcount[tid];
+            __syncthreads();
+        }
+        E* t = src;
+        src = dst;
+        dst = t;
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 template <int ES, int KPT>
 __global__ __launch_bounds__(512) void rsx_small_sort_kernel(const SmallArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -139,7 +253,6 @@ __global__ __launch_bounds__(512) void rsx_small_sort_kernel(const SmallArgs a) 
 template <int ES, int KPT>
 __global__ __launch_bounds__(1024) void rsx_bucket_sort_kernel(const SmallArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.mid_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 1) return;
     uint64_t* s_red = reinterpret_cast<uint64_t*>(smem);  // [4] partial sums, [4] the bucket's count
     const uint32_t tid = threadIdx.x, v = blockIdx.x;
     uint64_t c = 0;
@@ -165,8 +278,9 @@ __global__ __launch_bounds__(1024) void rsx_bucket_sort_kernel(const SmallArgs a
     const uint64_t count = s_red[4];
     __syncthreads();  // smem is the sort's from here
     if (count == 0) return;
-    if (count > (uint64_t)1024 * KPT) {  // the first sweep checked every bucket against this capacity
-        if (tid == 0) __hip_atomic_store(a.error, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (count > (uint64_t)1024 * KPT) {  // a skewed top digit the host did not foresee: through memory, by this workgroup alone
+        big_bucket_sort<ES, KPT, 1024>(a, const_cast<Elem<ES>*>(static_cast<const Elem<ES>*>(a.src)) + start,
+                                       static_cast<Elem<ES>*>(a.data) + start, (uint32_t)count, smem);
         return;
     }
     local_sort<ES, KPT, 1024>(a, static_cast<const Elem<ES>*>(a.src) + start, static_cast<Elem<ES>*>(a.data) + start,

@@ -95,6 +95,33 @@ def test_middle_sizes(rs, torch, ctx, orc, t):
         assert np.array_equal(_gpu_sort(rs, torch, ctx, raw, d), orc.sort_parallel(raw, lay, 8)), (t, n, dist)
 
 
+@pytest.mark.parametrize("t", ["u32", "u64", "(u64,u64)", "i16", "f32", "(u32,[u8;8])", "(u128,u128)"])
+def test_middle_size_forecast_and_oversized_buckets(rs, torch, orc, t):
+    """The host forecasts the bucket split from the previous sort's report.  On a fresh context: uniform (split), then
+    skewed inputs that the forecast gets wrong (the oversized buckets are sorted through memory by one workgroup each),
+    then the cool-down of LSD passes, then uniform again -- and every distribution with the split forced."""
+    d = _digits(rs, t)
+    lay = orc.Layout(*util.TYPES[t])
+    mm = _mid_max(d.elem_bytes)
+    c = rs.Context(torch.cuda.current_device())
+    seq = [(mm // 3, "uniform"), (mm // 3 + 1, "zipf"), (mm // 4, "uniform"), (mm // 5, "equal"), (mm // 3, "uniform")]
+    for i, (n, dist) in enumerate(seq * 3):  # 15 sorts: forecast right, wrong, cool-down, recovery
+        raw = util.make_input(t, n, dist, seed=500 + i)
+        x = torch.from_numpy(raw.copy()).cuda()
+        rs.radix_sort(x, digits=d, ctx=c)
+        c.check()
+        assert np.array_equal(x.cpu().numpy(), orc.sort_parallel(raw, lay, 8)), (t, i, n, dist)
+    c.set_option(rs.OPT_MID_SORT, 2)
+    for i, dist in enumerate(util.DISTS):
+        n = mm // 4 + 17 * i
+        raw = util.make_input(t, n, dist, seed=600 + i)
+        x = torch.from_numpy(raw.copy()).cuda()
+        rs.radix_sort(x, digits=d, ctx=c)
+        c.check()
+        assert np.array_equal(x.cpu().numpy(), orc.sort_parallel(raw, lay, 8)), (t, "forced split", n, dist)
+    c.close()
+
+
 @pytest.mark.parametrize("t", ["u32", "(u64,u64)", "i16", "f64"])
 @pytest.mark.parametrize("over", [0, 1])
 def test_middle_size_bucket_capacity_edge(rs, torch, ctx, orc, t, over):
@@ -353,7 +380,9 @@ ALT_PATHS = [("OPT_TILE_SCHEDULE", 1, "ticketed tiles instead of the static roll
              ("OPT_MAX_REGIONS", 32, "32 look-back chains"),
              ("OPT_HOT_LANES", 2, "every tile treated as skewed"),
              ("OPT_SMALL_SORT", 0, "arrays of at most one tile through the general path"),
-             ("OPT_MID_SORT", 0, "middle sizes by LSD passes only (no bucket split)")]
+             ("OPT_MID_SORT", 0, "middle sizes by LSD passes only (no bucket split)"),
+             ("OPT_MID_SORT", 2, "middle sizes always split by the top digit (skewed inputs: oversized buckets through memory)"),
+             ("OPT_MID_SORT", 3, "middle sizes always by LSD passes, top digit counted for the forecast")]
 
 
 @pytest.mark.parametrize("opt,value,what", ALT_PATHS)
