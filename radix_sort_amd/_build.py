@@ -22,7 +22,7 @@ LIBDIR = os.path.join(_HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "librsx.so")
 ELEM_SIZES = (1, 2, 4, 8, 12, 16, 24, 32)
-DEPS = ["rsx.hip", "rsx_es.hip", "rsx_device.hpp", "rsx_internal.hpp", "rsx_launch_impl.hpp", "rsx_misc_kernels.hpp",
+DEPS = ["rsx.hip", "rsx_es.hip", "rsx_device.hpp", "rsx_internal.hpp", "rsx_launch_impl.hpp", "rsx_misc_kernels.hpp", "rsx_small_kernel.hpp", "rsx_mid_kernels.hpp",
         os.path.join("..", "..", "include", "rsx.h")]
 CXXFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

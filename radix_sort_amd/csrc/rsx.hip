@@ -60,9 +60,28 @@ struct Enqueue {
     }
 };
 
+uint64_t mid_max_for(uint32_t es) {
+    switch (es) {
+        case 2: return mid_max_elems(2);
+        case 4: return mid_max_elems(4);
+        case 8: return mid_max_elems(8);
+        case 12: return mid_max_elems(12);
+        case 16: return mid_max_elems(16);
+        case 24: return mid_max_elems(24);
+        case 32: return mid_max_elems(32);
+        default: return 0;
+    }
+}
+
 size_t status_bytes_for(const rsx_ctx* ctx, size_t n, uint32_t es) {
     const RegionGeom g = make_geom(ctx, n, es);
-    return (size_t)status_rows(g, es) * RADIX * (status32(g) ? 4 : 8);
+    size_t b = (size_t)status_rows(g, es) * RADIX * (status32(g) ? 4 : 8);
+    if ((uint64_t)n <= mid_max_for(es)) {  // the bucket split of a middle-size sort has more, smaller tiles
+        const RegionGeom gs = make_geom(ctx, n, es, true);
+        const size_t bs = (size_t)status_rows(gs, es) * RADIX * 4;
+        if (bs > b) b = bs;
+    }
+    return b;
 }
 
 // First use of a context on its device: aux block, host-visible error word, the two device self-tests.
@@ -136,20 +155,11 @@ int hist2_dispatch(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx
                    unsigned long long* J, uint32_t digit2, unsigned long long* J2, unsigned long long* jclear, hipStream_t st) {
     RSX_DISPATCH_ES(L->elem_bytes, launch_hist2, ctx, src, g, L, digit, J, digit2, J2, jclear, st)
 }
+int mid_split_dispatch(rsx_ctx* ctx, const void* src, void* dst, size_t n, const rsx_layout* L, hipStream_t st) {
+    RSX_DISPATCH_ES(L->elem_bytes, launch_mid_split, ctx, src, dst, n, L, st)
+}
 int bucket_dispatch(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L, hipStream_t st) {
     RSX_DISPATCH_ES(L->elem_bytes, launch_bucket_sort, ctx, src, dst, g, L, st)
-}
-uint64_t mid_max_for(uint32_t es) {
-    switch (es) {
-        case 2: return mid_max_elems(2);
-        case 4: return mid_max_elems(4);
-        case 8: return mid_max_elems(8);
-        case 12: return mid_max_elems(12);
-        case 16: return mid_max_elems(16);
-        case 24: return mid_max_elems(24);
-        case 32: return mid_max_elems(32);
-        default: return 0;
-    }
 }
 int small_dispatch(rsx_ctx* ctx, void* data, size_t n, const rsx_layout* L, hipStream_t st) {
     RSX_DISPATCH_ES(L->elem_bytes, launch_small_sort, ctx, data, n, L, st)
@@ -172,20 +182,29 @@ int launch_totals(rsx_ctx* ctx, const RegionGeom& g, const unsigned long long* J
 // top digit's count matrix and count matrix 0, all zero -- and tells the count kernel which block to zero on its way:
 // the one the previous sort used (rsx_internal.hpp, aux layout).  A sort that is being captured into a graph uses
 // block 2 and zeroes it itself (a replay cannot alternate); so does the sort after a failed enqueue, for both blocks.
-int begin_control(rsx_ctx* ctx, hipStream_t st) {
-    ctx->clean16 = nullptr;
-    ctx->clean16_n = 0;
+int begin_control(rsx_ctx* ctx, hipStream_t st, const RegionGeom& g, bool uses_jt) {
+    ctx->clean = CleanList{{nullptr, nullptr, nullptr}, {0, 0, 0}};
+    const uint64_t used = (uint64_t)J_REPL * g.num_regions * RADIX * sizeof(uint64_t);  // prefix of a count matrix in use
     if (capturing(st)) {
         ctx->cb = 2;
         RSX_HIP(hipMemsetAsync(cb_of(ctx, 2), 0, CB_BYTES, st));
         return RSX_OK;
     }
-    if (ctx->cb_dirty) RSX_HIP(hipMemsetAsync(cb_of(ctx, 0), 0, 2 * CB_BYTES, st));
+    if (ctx->cb_dirty) {
+        RSX_HIP(hipMemsetAsync(cb_of(ctx, 0), 0, 2 * CB_BYTES, st));
+        ctx->cb_used[0][0] = ctx->cb_used[0][1] = ctx->cb_used[1][0] = ctx->cb_used[1][1] = 0;
+    }
     const uint32_t prev = ctx->cb_alt;
     ctx->cb_alt ^= 1u;
     ctx->cb = ctx->cb_alt;
-    ctx->clean16 = reinterpret_cast<uint4*>(cb_of(ctx, prev));
-    ctx->clean16_n = CB_BYTES / 16;
+    ctx->clean.p[0] = reinterpret_cast<uint4*>(cb_of(ctx, prev) + CB_TICKETS);
+    ctx->clean.n16[0] = CB_JT / 16;
+    ctx->clean.p[1] = reinterpret_cast<uint4*>(cb_of(ctx, prev) + CB_JT);
+    ctx->clean.n16[1] = ctx->cb_used[prev][0] / 16;
+    ctx->clean.p[2] = reinterpret_cast<uint4*>(cb_of(ctx, prev) + CB_J0);
+    ctx->clean.n16[2] = ctx->cb_used[prev][1] / 16;
+    ctx->cb_used[ctx->cb][0] = uses_jt ? used : 0;
+    ctx->cb_used[ctx->cb][1] = used;
     ctx->cb_dirty = true;  // until the enqueue has gone through (end_control)
     return RSX_OK;
 }
@@ -225,7 +244,6 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
     if (rc) return rc;
     Enqueue enq(ctx, st);
     const uint32_t D = L->key_bytes;  // T::NUMBER_OF_DIGITS
-    const RegionGeom geom = make_geom(ctx, n, L->elem_bytes);
     const bool counting_path = L->elem_bytes == 1 && !(ctx->options & OPT_GENERAL_BYTES);  // no sweep follows
     ctx->last_sort_passes = 0;
     // at most one tile: all D passes in one launch of one workgroup (rsx_small_kernel.hpp)
@@ -238,11 +256,10 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
     // returns at once, so the host FORECASTS from what the previous middle-size sort reported (a host-visible word,
     // read without synchronising: it may lag, and either way the result is right -- a bucket that does not fit after
     // all is sorted through memory by its one workgroup, slowly, after which the context keeps to LSD passes for a while).
-    const bool mid = !counting_path && D >= 2 && (uint64_t)n <= mid_max_for(L->elem_bytes) && geom.num_regions <= MID_MAX_REGIONS &&
-                     status32(geom) && !(ctx->options & OPT_NO_MID_SORT);
+    const bool mid = !counting_path && D >= 2 && (uint64_t)n <= mid_max_for(L->elem_bytes) && !(ctx->options & OPT_NO_MID_SORT);
     uint32_t mid_mode = 0;
     if (mid) {
-        const uint32_t hint = reinterpret_cast<volatile uint32_t*>(ctx->host_err)[8];  // 0 nothing yet, 1 fits, 2 does not
+        const uint32_t hint = reinterpret_cast<volatile uint32_t*>(ctx->host_err)[8];  // 0 nothing yet, 1 / 3 fits (a small / a large workgroup), 2 does not
         if (ctx->mid_choice == 1 && hint == 2 && ctx->mid_cooldown == 0) ctx->mid_cooldown = 8;  // a split met a skewed input
         if (ctx->mid_cooldown > 0) {
             --ctx->mid_cooldown;
@@ -252,10 +269,20 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
         }
         if (ctx->mid_force) mid_mode = ctx->mid_force;
         ctx->mid_choice = mid_mode;
+        ctx->bucket_small = hint == 1 && (uint64_t)n <= 256ull * 2048ull;
     }
-    // count phase of pass 0 (mod.rs:90-109); later passes are counted by the sweep before them
-    rc = begin_control(ctx, st);
+    if (mid_mode == 1) {  // bucket split (count, scan, scatter: rsx_mid_kernels.hpp), then every bucket sorted in LDS
+        const RegionGeom gs = make_geom(ctx, n, L->elem_bytes, true);
+        rc = mid_split_dispatch(ctx, d_data, d_tmp, n, L, st);  // the buckets are made in d_tmp (keys stay mapped) ...
+        if (rc) return rc;
+        rc = bucket_dispatch(ctx, d_tmp, d_data, gs, L, st);    // ... sorted, they land in d_data
+        if (rc) return rc;
+        return RSX_OK;
+    }
+    const RegionGeom geom = make_geom(ctx, n, L->elem_bytes);
+    rc = begin_control(ctx, st, geom, mid);
     if (rc) return rc;
+    // count phase of pass 0 (mod.rs:90-109); later passes are counted by the sweep before them
     if (mid) rc = hist2_dispatch(ctx, d_data, geom, L, 0, J_of(ctx, 0), D - 1, JT_of(ctx), J_of(ctx, 1), st);
     else rc = hist_dispatch(ctx, d_data, geom, L, 0, J_of(ctx, 0), D > 1 ? J_of(ctx, 1) : nullptr, !counting_path, st);
     if (rc) return rc;
@@ -284,17 +311,10 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
         const int xf = (d == 0 ? 1 : 0) | (d + 1 == D ? 2 : 0);  // key map on at the first, off at the last pass
         ctx->pass_index = d;
         ctx->pass_last = d + 1 == D;
-        ctx->pass_mid = d == 0 ? mid_mode : 0u;
+        ctx->pass_mid = d == 0 ? mid_mode : 0u;  // (2: the first LSD pass also reports whether the top digit's buckets would fit)
         rc = sweep_dispatch(ctx, src, dst, geom, L, d, J_of(ctx, d % 3), jnext, jzero, xf, st);  // mod.rs:121-168
         ctx->pass_mid = 0;
         if (rc) return rc;
-        if (mid_mode == 1) {  // the buckets were made in d_tmp; sorted, they land in d_data
-            rc = bucket_dispatch(ctx, d_tmp, d_data, geom, L, st);
-            if (rc) return rc;
-            ctx->last_sort_passes = 1;
-            end_control(ctx);
-            return RSX_OK;
-        }
     }
 
     if (D % 2 == 1)  // odd-D copy-back (mod.rs:170-174)
@@ -722,7 +742,7 @@ int rsx_histogram_device(rsx_ctx* ctx, const void* d_src, size_t n, const rsx_la
     if (rc) return rc;
     Enqueue enq(ctx, st);
     const RegionGeom geom = make_geom(ctx, n, L->elem_bytes);
-    rc = begin_control(ctx, st);
+    rc = begin_control(ctx, st, geom, false);
     if (rc) return rc;
     rc = hist_dispatch(ctx, d_src, geom, L, digit, J_of(ctx, 0), nullptr, false, st);
     if (rc) return rc;
@@ -742,7 +762,7 @@ int partition_locked(rsx_ctx* ctx, const void* d_src, void* d_dst, size_t n, con
     if (rc) return rc;
     Enqueue enq(ctx, st);
     const RegionGeom geom = make_geom(ctx, n, L->elem_bytes);
-    rc = begin_control(ctx, st);
+    rc = begin_control(ctx, st, geom, false);
     if (rc) return rc;
     rc = hist_dispatch(ctx, d_src, geom, L, digit, J_of(ctx, 0), nullptr, true, st);
     if (rc) return rc;

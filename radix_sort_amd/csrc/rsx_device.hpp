@@ -251,6 +251,14 @@ struct RegionGeom {
     uint64_t n;
     uint32_t region_shift;  // log2(elements per region): a multiple of the tile size
     uint32_t num_regions;   // ceil(n >> region_shift), 1..MAX_REGIONS
+    uint32_t tile;          // elements per tile of the sweeps that use this geometry (host side only)
+};
+
+// what the count kernel zeroes on its way, beside its own sort's status words: the parts of the PREVIOUS sort's control
+// block that it used (control words, top-digit count matrix, count matrix 0): rsx.hip begin_control
+struct CleanList {
+    uint4* p[3];
+    uint64_t n16[3];
 };
 
 // --------------------------------------------------------------- histogram --
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restric
                                                        unsigned long long* __restrict__ J,
                                                        unsigned long long* __restrict__ jclear, uint32_t j32,
                                                        uint4* __restrict__ zero16, uint64_t zero16_n,
-                                                       uint4* __restrict__ zero16b, uint64_t zero16b_n,
+                                                       CleanList clean,
                                                        DigitSpec spec2 = DigitSpec{}, unsigned long long* __restrict__ J2 = nullptr) {
     __shared__ uint32_t lh[TWO ? 2 * RADIX : RADIX];
     const uint32_t tid = threadIdx.x;
@@ -290,8 +298,10 @@ __global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restric
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + tid; i < zero16_n; i += (uint64_t)gridDim.x * blockDim.x)
         zero16[i] = make_uint4(0, 0, 0, 0);
     // ... and the control block the PREVIOUS sort on this context used (the next one will find it clean: no memset launch)
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + tid; i < zero16b_n; i += (uint64_t)gridDim.x * blockDim.x)
-        zero16b[i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int z = 0; z < 3; ++z)
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + tid; i < clean.n16[z]; i += (uint64_t)gridDim.x * blockDim.x)
+            clean.p[z][i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const uint32_t r = blockIdx.x / blocks_per_region;
     const uint32_t sub = blockIdx.x % blocks_per_region;
@@ -766,7 +776,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         uint64_t big = s_scan[0];
 #pragma unroll
         for (int w = 1; w < RADIX / WAVE; ++w) big = s_scan[w] > big ? s_scan[w] : big;
-        const bool fits = __builtin_amdgcn_readfirstlane((int)(big <= (uint64_t)a.mid_cap)) != 0;
+        const uint32_t fits = (uint32_t)__builtin_amdgcn_readfirstlane((int)(big <= (uint64_t)a.mid_cap / 4 ? 1u : big <= (uint64_t)a.mid_cap ? 3u : 2u));
         msd = a.mid_mode == 1u;
         __syncthreads();  // s_half / s_scan are used again by scan_cursors
         if (msd) {
@@ -775,7 +785,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         } else {
             load_counts(a.J, home, tot_home, below_home);
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.mid_hint, fits ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.mid_hint, fits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     } else {
         load_counts(a.J, home, tot_home, below_home);
     }

@@ -11,6 +11,7 @@ template int launch_hist<RSX_ES>(rsx_ctx*, const void*, const RegionGeom&, const
                                  unsigned long long*, unsigned long long*, bool, hipStream_t);
 template int launch_hist2<RSX_ES>(rsx_ctx*, const void*, const RegionGeom&, const rsx_layout*, uint32_t, unsigned long long*,
                                   uint32_t, unsigned long long*, unsigned long long*, hipStream_t);
+template int launch_mid_split<RSX_ES>(rsx_ctx*, const void*, void*, size_t, const rsx_layout*, hipStream_t);
 template int launch_bucket_sort<RSX_ES>(rsx_ctx*, const void*, void*, const RegionGeom&, const rsx_layout*, hipStream_t);
 template int launch_sweep<RSX_ES>(rsx_ctx*, const void*, void*, const RegionGeom&, const rsx_layout*, uint32_t,
                                   const unsigned long long*, unsigned long long*, unsigned long long*, int, hipStream_t);

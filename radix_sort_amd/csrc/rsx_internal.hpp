@@ -35,7 +35,7 @@ constexpr int MAX_PASSES = 16;                                                  
 constexpr size_t J_BYTES = (size_t)J_REPL * MAX_REGIONS * RADIX * sizeof(uint64_t);  // one count matrix, all replicas
 constexpr size_t TICKET_WORDS = ROLL_SHARDS + (size_t)ROLL_SHARD_COUNT * ROLL_SHARD_STRIDE;  // per pass (rsx_device.hpp)
 constexpr uint32_t PART_MAX_SUB = 16;  // sub-ranges of rsx_partition_count_device / rsx_partition_scatter_device
-constexpr uint32_t MID_MAX_REGIONS = 8;  // middle-size sorts: regions of the most significant digit's count matrix
+constexpr uint32_t MID_MAX_REGIONS = 16;  // middle-size sorts: regions of the most significant digit's count matrix
 constexpr size_t CB_TICKETS = 0;                                                 // [MAX_PASSES][TICKET_WORDS] u32
 constexpr size_t CB_JT = ((MAX_PASSES * TICKET_WORDS * 4 + 255) / 256) * 256;    // count matrix of the most significant digit
 constexpr size_t JT_BYTES = (size_t)J_REPL * MID_MAX_REGIONS * RADIX * sizeof(uint64_t);
@@ -94,8 +94,8 @@ struct rsx_ctx {
     uint32_t pass_index = 0;   // of the sweep being launched within its sort (selects the status half, J rotation)
     bool pass_last = true;     // no pass follows: nothing to clean
     uint32_t last_sort_passes = 0;  // sweep passes of the last sort (RSX_INFO_LAST_PASSES)
-    uint4* clean16 = nullptr;  // what the next count kernel zeroes on its way (the previous sort's control block)
-    uint64_t clean16_n = 0;
+    rsx::CleanList clean = {{nullptr, nullptr, nullptr}, {0, 0, 0}};  // what the next count kernel zeroes on its way (the previous sort's control block)
+    uint64_t cb_used[2][2] = {{0, 0}, {0, 0}};  // per alternating block: bytes of the top-digit matrix / of count matrix 0 its last sort used
     uint32_t cb_alt = 0;       // which of the two alternating blocks the last uncaptured sort used
     uint32_t* tickets_override = nullptr;  // rsx_partition_scatter_device: control words outside the blocks
     uint32_t cb = 0;           // control block of the sort being enqueued (aux layout above)
@@ -103,6 +103,7 @@ struct rsx_ctx {
     bool cb_dirty = false;     // an enqueue failed half way: both alternating blocks are zeroed by memset before the next sort
     uint32_t pass_mid = 0;     // middle-size sort, first sweep (MID instantiation): 1 = bucket split by the top digit, 2 = first LSD pass
     uint32_t mid_choice = 0;   // what the last middle-size sort was enqueued as (1 / 2)
+    bool bucket_small = false; // the bucket kernel being launched: 256-thread workgroups
     uint32_t mid_force = 0;    // RSX_OPT_MID_SORT 2 / 3: always split (1) / always LSD passes (2)
     uint32_t mid_cooldown = 0; // sorts to go by LSD passes after a bucket split met a skewed input
     bool rank_atomic = false;  // LDS atomic ordering self-test passed (set when the workspace is first made)
@@ -213,31 +214,37 @@ constexpr uint64_t mid_max_elems(int es) { return (uint64_t)bucket_cap(es) * 256
 constexpr int kpt_for(int es) { return es <= 2 ? RSX_KPT2 : es <= 4 ? RSX_KPT4 : es == 8 ? RSX_KPT8 : es == 12 ? RSX_KPT12 : es == 16 ? RSX_KPT16 : es == 24 ? RSX_KPT24 : RSX_KPT32; }
 constexpr int wg_for(int es) { return es <= 4 ? RSX_WG4 : es == 8 ? RSX_WG8 : 512; }
 constexpr uint32_t tile_elems(int es) { return wg_for(es) * kpt_for(es); }
+// The bucket split of a middle-size sort runs the sweep with SMALL tiles (a tile is one workgroup's serial work: 13 us
+// for 14336 u32 keys, and 2^16 keys are five of those) and more, shorter chains (it counts nothing for a next pass,
+// so regions cost it no LDS and no flush): 512 x 8 4-byte, 512 x 4 8-byte, 512 x 2 16-byte elements.
+constexpr int mid_kpt_for(int es) { return es <= 4 ? 8 : es == 8 ? 4 : es == 12 ? 3 : 2; }
+constexpr uint32_t mid_tile_elems(int es) { return 512u * (uint32_t)mid_kpt_for(es); }
 
 inline uint32_t log2u(uint64_t x) { return 63u - (uint32_t)__builtin_clzll(x); }
 
 // Regions: smallest power-of-two length (>= one tile) that covers n with <= cap of them.
-inline RegionGeom make_geom(const rsx_ctx* ctx, uint64_t n, uint32_t es) {
+// small_tiles: the geometry of a middle-size sort's bucket split (mid_tile_elems, regions from 8 tiles on, up to 16).
+inline RegionGeom make_geom(const rsx_ctx* ctx, uint64_t n, uint32_t es, bool small_tiles = false) {
     RegionGeom g;
     g.n = n;
-    uint32_t k = log2u(tile_elems((int)es));
-    if ((1ull << k) < tile_elems((int)es)) ++k;  // tiles need not be a power of two; regions are
+    g.tile = small_tiles ? mid_tile_elems((int)es) : tile_elems((int)es);
+    uint32_t k = log2u(g.tile);
+    if ((1ull << k) < g.tile) ++k;  // tiles need not be a power of two; regions are
     // A region is worth having from about 64 tiles on: every region ends with a partial tile and a workgroup of its
     // own, and widens every workgroup's count-matrix flush.  Measured with one region per 2^k keys: 2^18 u32
     // 109 -> 87 us, 2^22 u32 148 -> 134 us, 2^18 u64 249 -> 166 us, 2^22 u64 360 -> 275 us; large inputs are
     // bounded by `cap` as before.
-    k += RSX_REGION_FLOOR;
+    k += small_tiles ? 3 : RSX_REGION_FLOOR;
     // the next pass's count matrix costs 1 KiB of LDS per region: 8 where the tile needs the room
-    const uint64_t cap = ctx->max_regions ? ctx->max_regions : (es == 8 || es == 32) ? 16 : 8;
+    const uint64_t cap = small_tiles ? MID_MAX_REGIONS : ctx->max_regions ? ctx->max_regions : (es == 8 || es == 32) ? 16 : 8;
     while (((n + (1ull << k) - 1) >> k) > cap) ++k;
     g.region_shift = k;
     g.num_regions = (uint32_t)((n + (1ull << k) - 1) >> k);
     if (g.num_regions == 0) g.num_regions = 1;
     return g;
 }
-inline uint64_t tiles_per_region(const RegionGeom& g, uint32_t es) {
-    const uint64_t t = tile_elems((int)es);
-    return ((1ull << g.region_shift) + t - 1) / t;
+inline uint64_t tiles_per_region(const RegionGeom& g, uint32_t) {
+    return ((1ull << g.region_shift) + g.tile - 1) / g.tile;
 }
 inline uint64_t status_rows(const RegionGeom& g, uint32_t es) {
     return (uint64_t)g.num_regions * tiles_per_region(g, es);
@@ -291,6 +298,9 @@ int launch_hist(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_la
 template <int ES>
 int launch_hist2(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_layout* L, uint32_t digit,
                  unsigned long long* J, uint32_t digit2, unsigned long long* J2, unsigned long long* jclear, hipStream_t st);
+// first half of a middle-size sort: stable split of `src` into `dst` by the most significant digit (three launches)
+template <int ES>
+int launch_mid_split(rsx_ctx* ctx, const void* src, void* dst, size_t n, const rsx_layout* L, hipStream_t st);
 // second half of a middle-size sort: the 256 top-digit buckets of `src` sorted by the lower digits into `dst`
 template <int ES>
 int launch_bucket_sort(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L, hipStream_t st);

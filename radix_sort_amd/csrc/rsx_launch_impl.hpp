@@ -3,6 +3,7 @@
 #pragma once
 #include "rsx_internal.hpp"
 #include "rsx_small_kernel.hpp"
+#include "rsx_mid_kernels.hpp"
 
 #ifndef RSX_HIST_BLOCKS_PER_CU
 #define RSX_HIST_BLOCKS_PER_CU 8
@@ -24,10 +25,9 @@ int launch_hist_t(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_
     LaunchTimer lt(ctx, RSX_PROF_HIST, st);
     hipLaunchKernelGGL((rsx_hist_kernel<ES, FLT>), dim3((uint32_t)(bpr * g.num_regions)), dim3(512), 0, st,
                        static_cast<const Elem<ES>*>(src), g, make_spec(L, digit), (uint32_t)bpr, J, jclear, status32(g) ? 1u : 0u,
-                       static_cast<uint4*>(ctx->status), zero16_n, ctx->clean16, ctx->clean16_n);
+                       static_cast<uint4*>(ctx->status), zero16_n, ctx->clean);
     RSX_HIP(hipGetLastError());
-    ctx->clean16 = nullptr;  // done once per sort
-    ctx->clean16_n = 0;
+    ctx->clean = CleanList{{nullptr, nullptr, nullptr}, {0, 0, 0}};  // done once per sort
     return RSX_OK;
 }
 template <int ES>
@@ -52,14 +52,13 @@ int launch_hist2(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_l
     if (L->key_kind != RSX_KEY_UNSIGNED)
         hipLaunchKernelGGL((rsx_hist_kernel<ES, true, true>), dim3((uint32_t)(bpr * g.num_regions)), dim3(512), 0, st,
                            static_cast<const Elem<ES>*>(src), g, make_spec(L, digit), (uint32_t)bpr, J, jclear, status32(g) ? 1u : 0u,
-                           static_cast<uint4*>(ctx->status), zero16_n, ctx->clean16, ctx->clean16_n, make_spec(L, digit2), J2);
+                           static_cast<uint4*>(ctx->status), zero16_n, ctx->clean, make_spec(L, digit2), J2);
     else
         hipLaunchKernelGGL((rsx_hist_kernel<ES, false, true>), dim3((uint32_t)(bpr * g.num_regions)), dim3(512), 0, st,
                            static_cast<const Elem<ES>*>(src), g, make_spec(L, digit), (uint32_t)bpr, J, jclear, status32(g) ? 1u : 0u,
-                           static_cast<uint4*>(ctx->status), zero16_n, ctx->clean16, ctx->clean16_n, make_spec(L, digit2), J2);
+                           static_cast<uint4*>(ctx->status), zero16_n, ctx->clean, make_spec(L, digit2), J2);
     RSX_HIP(hipGetLastError());
-    ctx->clean16 = nullptr;
-    ctx->clean16_n = 0;
+    ctx->clean = CleanList{{nullptr, nullptr, nullptr}, {0, 0, 0}};
     return RSX_OK;
 }
 
@@ -84,11 +83,12 @@ inline KeyXform make_xform(const rsx_layout* L) {
     return x;
 }
 
-template <int ES, typename S, int XF, bool NEXT, bool MID = false>
+template <int ES, typename S, int XF, bool NEXT, bool MID = false, bool SMALLT = false>
 int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L,
                    uint32_t digit, const unsigned long long* J, unsigned long long* jnext, unsigned long long* jzero,
                    hipStream_t st) {
-    constexpr int KPT = kpt_for(ES);
+    constexpr int KPT = SMALLT ? mid_kpt_for(ES) : kpt_for(ES);
+    if (g.tile != (uint32_t)(wg_for(ES) * KPT)) return fail(ctx, RSX_ERR_INTERNAL, "launch_sweep: geometry of another tile size");
     constexpr int SWEEP_WG = wg_for(ES);
     constexpr int TILE = SWEEP_WG * KPT;
     const uint64_t rows = status_rows(g, ES);
@@ -203,6 +203,10 @@ template <int ES, typename S, int XF>
 int launch_sweep_n(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L,
                    uint32_t digit, const unsigned long long* J, unsigned long long* jnext, unsigned long long* jzero,
                    hipStream_t st) {
+    if constexpr ((XF & 2) == 0 && sizeof(S) == 4 && ES != 1) {  // the bucket split of a middle-size sort: small tiles
+        if (!jnext && g.tile == mid_tile_elems(ES) && mid_tile_elems(ES) != tile_elems(ES))
+            return launch_sweep_t<ES, S, XF, false, false, true>(ctx, src, dst, g, L, digit, J, nullptr, jzero, st);
+    }
     if constexpr ((XF & 2) == 0) {  // a pass that maps the keys back is a last pass: nothing to count for
         if constexpr (sizeof(S) == 4 && ES != 1) {  // the first sweep of a middle-size sort (regions of <= 2^30 elements by far)
             if (jnext && ctx->pass_mid != 0) return launch_sweep_t<ES, S, XF, true, true>(ctx, src, dst, g, L, digit, J, jnext, jzero, st);
@@ -260,7 +264,50 @@ int launch_small_sort(rsx_ctx* ctx, void* data, size_t n, const rsx_layout* L, h
     return RSX_OK;
 }
 
-// ---- middle-size sorts: the 256 top-digit buckets, each sorted by one workgroup ------------------
+// ---- middle-size sorts: split by the top digit (count -> scan -> scatter, one launch each) --------
+inline uint32_t* mid_totals_of(rsx_ctx* ctx) { return reinterpret_cast<uint32_t*>(ctx->aux + OFF_BASE); }
+template <int ES>
+int launch_mid_split(rsx_ctx* ctx, const void* src, void* dst, size_t n, const rsx_layout* L, hipStream_t st) {
+    if constexpr (ES == 1) {
+        return fail(ctx, RSX_ERR_INTERNAL, "launch_mid_split: one-byte elements");
+    } else {
+        constexpr int KPT = mid_kpt_for(ES);
+        constexpr uint32_t TILE = 512u * KPT;
+        MidArgs a;
+        std::memset(&a, 0, sizeof a);
+        a.src = src;
+        a.dst = dst;
+        a.n = (uint32_t)n;
+        a.tiles = (uint32_t)((n + TILE - 1) / TILE);
+        if ((size_t)a.tiles * RADIX * sizeof(uint32_t) > ctx->status_bytes) return fail(ctx, RSX_ERR_INTERNAL, "launch_mid_split: workspace");
+        a.C = static_cast<uint32_t*>(ctx->status);
+        a.X = reinterpret_cast<uint32_t*>(static_cast<char*>(ctx->status) + ctx->status_bytes);
+        a.T = mid_totals_of(ctx);
+        a.spec = make_spec(L, L->key_bytes - 1);  // count: the raw key's top byte through the digit map
+        a.xf = make_xform(L);
+        a.map_keys = L->key_kind == RSX_KEY_UNSIGNED ? 0u : 1u;
+        a.rank_atomic = (ctx->rank_atomic && !(ctx->options & OPT_BALLOT_RANKS)) ? 1u : 0u;
+        {
+            LaunchTimer lt(ctx, RSX_PROF_HIST, st);
+            if (L->key_kind != RSX_KEY_UNSIGNED) hipLaunchKernelGGL((rsx_tilecount_kernel<ES, KPT, true>), dim3(a.tiles), dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((rsx_tilecount_kernel<ES, KPT, false>), dim3(a.tiles), dim3(512), 0, st, a);
+            RSX_HIP(hipGetLastError());
+        }
+        {
+            LaunchTimer lt(ctx, RSX_PROF_SCAN, st);
+            hipLaunchKernelGGL(rsx_tilescan_kernel<ES>, dim3(RADIX), dim3(256), 0, st, a);
+            RSX_HIP(hipGetLastError());
+        }
+        a.spec.flip = 0;  // scatter: the keys are mapped on load, plain digits from there on
+        const size_t lds = (size_t)TILE * ES + 8 * RADIX * sizeof(uint32_t) + 64 + 2 * RADIX * sizeof(uint32_t);
+        LaunchTimer lt(ctx, RSX_PROF_OTHER, st);
+        hipLaunchKernelGGL((rsx_tilescatter_kernel<ES, KPT>), dim3(a.tiles), dim3(512), lds, st, a);
+        RSX_HIP(hipGetLastError());
+        return RSX_OK;
+    }
+}
+
+// ---- ... then the 256 buckets, each sorted by one workgroup --------------------------------------
 template <int ES>
 int launch_bucket_sort(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L, hipStream_t st) {
     if constexpr (ES == 1) {
@@ -281,18 +328,24 @@ int launch_bucket_sort(rsx_ctx* ctx, const void* src, void* dst, const RegionGeo
             a.spec[d].flip = 0;
         }
         a.xf = make_xform(L);
-        a.top_J = JT_of(ctx);
-        a.num_regions = g.num_regions;
-        a.j32 = status32(g) ? 1u : 0u;
-        const size_t lds = (size_t)1024 * KPT * ES + 16 * RADIX * sizeof(uint32_t) + 64 + 3 * RADIX * sizeof(uint32_t);
-        auto kern = rsx_bucket_sort_kernel<ES, KPT>;
-        static thread_local bool attr_set = false;
-        if (!attr_set) {  // more than 64 KiB of dynamic LDS has to be asked for
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
-        }
+        (void)g;
+        a.top_tot = mid_totals_of(ctx);
+        a.cap = bucket_cap(ES);
+        a.hint = ctx->host_err_dev + 8;
         LaunchTimer lt(ctx, RSX_PROF_OTHER, st);
-        hipLaunchKernelGGL(kern, dim3(RADIX), dim3(1024), lds, st, a);
+        if (ctx->bucket_small) {  // small buckets, all known to fit: 256 threads each
+            const size_t lds = (size_t)256 * KPT * ES + 4 * RADIX * sizeof(uint32_t) + 64 + 3 * RADIX * sizeof(uint32_t);
+            hipLaunchKernelGGL((rsx_bucket_sort_kernel<ES, KPT, 256>), dim3(RADIX), dim3(256), lds, st, a);
+        } else {
+            const size_t lds = (size_t)1024 * KPT * ES + 16 * RADIX * sizeof(uint32_t) + 64 + 3 * RADIX * sizeof(uint32_t);
+            auto kern = rsx_bucket_sort_kernel<ES, KPT, 1024>;
+            static thread_local bool attr_set = false;
+            if (!attr_set) {  // more than 64 KiB of dynamic LDS has to be asked for
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(kern, dim3(RADIX), dim3(1024), lds, st, a);
+        }
         RSX_HIP(hipGetLastError());
         return RSX_OK;
     }

@@ -30,9 +30,10 @@ struct SmallArgs {
     DigitSpec spec[16];    // digit of pass d of the MAPPED key (flip == 0)
     KeyXform xf;
     // bucket kernel only
-    const unsigned long long* top_J;  // count matrix of the top digit, [J_REPL][num_regions][256]
-    uint32_t num_regions;
-    uint32_t j32;                     // its entries are 32 bit
+    const uint32_t* top_tot;          // the 256 totals of the top digit (rsx_tilescan_kernel)
+    uint32_t cap;                     // elements a 1024-thread workgroup sorts in LDS (a 256-thread one: a quarter)
+    uint32_t* hint;                   // host-visible report for the host's next forecast: 1 = every bucket of this input fits a
+                                      // 256-thread workgroup, 3 = a 1024-thread one, 2 = some bucket fits neither
 };
 
 // Sorts elements [0, n) of `src` by `a.passes` digits into `dst` (same index range), n <= WG * KPT.
@@ -248,26 +249,27 @@ __global__ __launch_bounds__(512) void rsx_small_sort_kernel(const SmallArgs a) 
 }
 
 // grid = 256: workgroup v sorts the bucket of top-digit value v, [start_v, start_v + count_v) of the partitioned
-// array, by the lower digits.  The bucket's place comes from the top digit's count matrix (every workgroup sums
-// the columns itself: L2-resident, J_REPL * num_regions loads per thread).
-template <int ES, int KPT>
-__global__ __launch_bounds__(1024) void rsx_bucket_sort_kernel(const SmallArgs a) {
+// array, by the lower digits.  The bucket's place comes from the 256 totals of the top digit.
+// WG: 1024 threads, or 256 for small buckets (n / 256 <= 2048 and the forecast says they all fit 256 x KPT): fewer
+// waves to scan and to wait for at the barriers -- 2^16 u32 keys 15.9 -> ~10 us.
+template <int ES, int KPT, int WG>
+__global__ __launch_bounds__(WG) void rsx_bucket_sort_kernel(const SmallArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t* s_red = reinterpret_cast<uint64_t*>(smem);  // [4] partial sums, [4] the bucket's count
+    uint64_t* s_red = reinterpret_cast<uint64_t*>(smem);  // [0..3] partial sums, [4] the bucket's count, [5..8] partial maxima
     const uint32_t tid = threadIdx.x, v = blockIdx.x;
     uint64_t c = 0;
     if (tid < RADIX) {
-        const uint32_t rows = (uint32_t)J_REPL * a.num_regions;
-        for (uint32_t r0 = 0; r0 < rows; r0 += 8) {  // rows is a multiple of 8 (J_REPL == 8)
-            uint64_t part[8];
-#pragma unroll
-            for (uint32_t k = 0; k < 8; ++k)
-                part[k] = a.j32 ? (uint64_t)reinterpret_cast<const uint32_t*>(a.top_J)[(r0 + k) * RADIX + tid]
-                                : (uint64_t)a.top_J[(r0 + k) * RADIX + tid];
-#pragma unroll
-            for (uint32_t k = 0; k < 8; ++k) c += part[k];
-        }
+        c = a.top_tot[tid];
         if (tid == v) s_red[4] = c;
+        if (v == 0) {  // workgroup 0 reports the largest bucket
+            uint64_t big = c;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint64_t y = __shfl_xor(big, o);
+                big = y > big ? y : big;
+            }
+            if ((tid & 63u) == 0u) s_red[5 + (tid >> 6)] = big;
+        }
         uint64_t below = tid < v ? c : 0ull;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o);
@@ -276,14 +278,19 @@ __global__ __launch_bounds__(1024) void rsx_bucket_sort_kernel(const SmallArgs a
     __syncthreads();
     const uint64_t start = s_red[0] + s_red[1] + s_red[2] + s_red[3];
     const uint64_t count = s_red[4];
+    if (v == 0 && tid == 0) {
+        uint64_t big = s_red[5];
+        for (int w = 1; w < 4; ++w) big = s_red[5 + w] > big ? s_red[5 + w] : big;
+        __hip_atomic_store(a.hint, big <= (uint64_t)a.cap / 4 ? 1u : big <= (uint64_t)a.cap ? 3u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __syncthreads();  // smem is the sort's from here
     if (count == 0) return;
-    if (count > (uint64_t)1024 * KPT) {  // a skewed top digit the host did not foresee: through memory, by this workgroup alone
-        big_bucket_sort<ES, KPT, 1024>(a, const_cast<Elem<ES>*>(static_cast<const Elem<ES>*>(a.src)) + start,
-                                       static_cast<Elem<ES>*>(a.data) + start, (uint32_t)count, smem);
+    if (count > (uint64_t)WG * KPT) {  // a skewed top digit the host did not foresee: through memory, by this workgroup alone
+        big_bucket_sort<ES, KPT, WG>(a, const_cast<Elem<ES>*>(static_cast<const Elem<ES>*>(a.src)) + start,
+                                     static_cast<Elem<ES>*>(a.data) + start, (uint32_t)count, smem);
         return;
     }
-    local_sort<ES, KPT, 1024>(a, static_cast<const Elem<ES>*>(a.src) + start, static_cast<Elem<ES>*>(a.data) + start,
+    local_sort<ES, KPT, WG>(a, static_cast<const Elem<ES>*>(a.src) + start, static_cast<Elem<ES>*>(a.data) + start,
                               (uint32_t)count, smem);
 }
 
