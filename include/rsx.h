@@ -99,7 +99,8 @@ enum {
     RSX_OPT_STATUS_SCOPE = 3,  /* 0 (default): look-back status words of a verified single-XCD chain stay in
                                   that XCD's L2; 1: agent-scope stores everywhere */
     RSX_OPT_XCD_MAJOR = 4,     /* 1 (default): workgroups numbered XCD-major; 0: by blockIdx */
-    RSX_OPT_BYTE_COUNTING = 5, /* 1 (default): u8/i8 arrays by counting; 0: through the general pass */
+    RSX_OPT_BYTE_COUNTING = 5, /* 1 (default): u8/i8 arrays, and u16/i16 arrays of at least 2^23 elements, by counting
+                                  (the element is its key: the histogram is the sorted array); 0: through the general passes */
     RSX_OPT_MAX_REGIONS = 6,   /* 0 (default: 8 or 16 by element size) .. 32 look-back chains per pass */
     RSX_OPT_HOT_LANES = 7,     /* 2..65 (default 16): lanes sharing a digit that mark a tile as skewed */
     RSX_OPT_VERBOSE = 8,       /* 1: launch geometry and self-test verdicts on stderr (also env RSX_VERBOSE=1) */

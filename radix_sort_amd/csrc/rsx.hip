@@ -249,6 +249,44 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
     // at most one tile: all D passes in one launch of one workgroup (rsx_small_kernel.hpp)
     if (!counting_path && n <= (size_t)512 * kpt_for((int)L->elem_bytes) && !(ctx->options & OPT_NO_SMALL_SORT))  // one 512-thread tile
         return small_dispatch(ctx, d_data, n, L, st);
+    // u16 / i16 arrays of at least 2^23 elements: the element is its two-byte key, so the 65536 counts ARE the sorted
+    // array: count (one read), write the runs (one write) -- instead of D = 2 passes of each.  The count kernel's
+    // per-workgroup counters (128 KiB each), the bin totals and the bin-block sums live in d_tmp.
+    if (L->elem_bytes == 2 && L->key_bytes == 2 && n >= ((size_t)1 << 23) && !(ctx->options & OPT_GENERAL_BYTES) &&
+        (ctx->ovf16 != nullptr || !capturing(st))) {
+        if (!ctx->ovf16) {
+            RSX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->ovf16), 65536 * sizeof(uint32_t)));
+            RSX_HIP(hipMemsetAsync(ctx->ovf16, 0, 65536 * sizeof(uint32_t), st));  // kept all zero between sorts by rsx_total16_kernel
+        }
+        const size_t tail = 65536 * sizeof(uint64_t) + 256 * sizeof(uint64_t);
+        size_t parts = (n * 2 - tail) / (32768 * sizeof(uint32_t));
+        if (parts > (size_t)ctx->num_cu) parts = (size_t)ctx->num_cu;
+        uint32_t* P = static_cast<uint32_t*>(d_tmp);
+        uint64_t* tot = reinterpret_cast<uint64_t*>(static_cast<char*>(d_tmp) + parts * 32768 * sizeof(uint32_t));
+        uint64_t* BT = tot + 65536;
+        const uint32_t xor_mask = L->key_kind == RSX_KEY_SIGNED ? 0x8000u : 0u;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rsx_count16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            attr_set = true;
+        }
+        {
+            LaunchTimer lt(ctx, RSX_PROF_HIST, st);
+            hipLaunchKernelGGL(rsx_count16_kernel, dim3((uint32_t)parts), dim3(1024), 131072, st, static_cast<const uint16_t*>(d_data),
+                               (uint64_t)n, xor_mask, P, ctx->ovf16);
+            RSX_HIP(hipGetLastError());
+        }
+        {
+            LaunchTimer lt(ctx, RSX_PROF_SCAN, st);
+            hipLaunchKernelGGL(rsx_total16_kernel, dim3(256), dim3(256), 0, st, P, (uint32_t)parts, ctx->ovf16, tot, BT);
+            RSX_HIP(hipGetLastError());
+        }
+        LaunchTimer lt(ctx, RSX_PROF_OTHER, st);
+        hipLaunchKernelGGL(rsx_expand16_kernel, dim3((uint32_t)ctx->num_cu * 8), dim3(256), 0, st, static_cast<uint16_t*>(d_data), (uint64_t)n, tot,
+                           BT, xor_mask);
+        RSX_HIP(hipGetLastError());
+        return RSX_OK;
+    }
     // Middle sizes (more than one tile, up to mid_max_elems): the count kernel also counts the MOST significant digit.
     // If that digit spreads the array over its 256 buckets so that each fits a workgroup's LDS, one sweep makes the
     // buckets and rsx_bucket_sort_kernel sorts each by the remaining digits: 4 launches and two trips through memory
@@ -400,6 +438,7 @@ int rsx_ctx_destroy(rsx_ctx* ctx) try {
         for (hipEvent_t e : ctx->copy_event)
             if (e) (void)hipEventDestroy(e);
         if (ctx->part_J) (void)hipFree(ctx->part_J);
+        if (ctx->ovf16) (void)hipFree(ctx->ovf16);
         if (ctx->shard_q) (void)hipFree(ctx->shard_q);
         if (ctx->shard_out) (void)hipFree(ctx->shard_out);
         if (ctx->shard_hist) (void)hipFree(ctx->shard_hist);

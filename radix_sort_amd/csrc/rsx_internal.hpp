@@ -83,6 +83,7 @@ struct rsx_ctx {
     void* pinned[4] = {nullptr, nullptr, nullptr, nullptr};  // ring of pinned bounce chunks
     hipEvent_t copy_event[4] = {nullptr, nullptr, nullptr, nullptr};
     // multi-GPU driver (rsx_sort_sharded): per-slice stream and splitter-search scratch, made once
+    uint32_t* ovf16 = nullptr;  // u16 / i16 counting path: 65536 overflow counters, all zero between sorts
     unsigned long long* part_J = nullptr;  // rsx_partition_count_device: one count matrix per sub-range (PART_MAX_SUB x J_BYTES)
     hipStream_t shard_stream = nullptr;
     uint64_t* shard_q = nullptr;     // device: queries (lo, hi) + ranges (begin, end)

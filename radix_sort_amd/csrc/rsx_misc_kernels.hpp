@@ -105,6 +105,220 @@ __global__ __launch_bounds__(256) void rsx_expand_bytes_kernel(uint8_t* __restri
     }
 }
 
+// ------------------------------------------------------------ two-byte elements --
+// An element that IS its two-byte key (u16, i16) is fully described by its 65536-bin histogram: count, then write the
+// runs (one read and one write of the data instead of D = 2 passes of each; same bytes as mod.rs:84-169 leaves).
+//
+// rsx_count16_kernel: one workgroup per CU keeps all 65536 counters in LDS as 16-bit halves of 32768 words (128 KiB) and
+// counts its contiguous share of the input with RETURNED atomics: the lane whose add takes a counter from 0x7FFF to
+// 0x8000 moves 0x8000 of it to a global overflow table (one lane per 32768 increments of a bin sees that value, and a
+// counter cannot run from 0x8000 to 0x10000 before that lane's subtraction lands: at most a few thousand adds are
+// in flight), so no counter ever carries into its neighbour, whatever the skew.  At the end the workgroup stores its
+// counters: P[workgroup][32768].  bin = key ^ xor_mask (0x8000 for signed keys: radix_digits.rs:55-69).
+__global__ __launch_bounds__(1024) void rsx_count16_kernel(const uint16_t* __restrict__ src, uint64_t n, uint32_t xor_mask,
+                                                           uint32_t* __restrict__ P, uint32_t* __restrict__ ovf) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem16);  // [32768]
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < 32768u / 4u; i += 1024u) reinterpret_cast<uint4*>(cnt)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    auto park = [&](uint32_t bin, uint32_t sh) {  // the add that took a counter to (or over) 0x8000 moves that half to the overflow table
+        atomicSub(&cnt[bin >> 1], 0x8000u << sh);
+        atomicAdd(&ovf[bin], 0x8000u);
+    };
+    auto count = [&](uint32_t key) {
+        const uint32_t bin = (key ^ xor_mask) & 0xFFFFu;
+        const uint32_t sh = (bin & 1u) * 16u;
+        const uint32_t old = atomicAdd(&cnt[bin >> 1], 1u << sh);
+        if (((old >> sh) & 0xFFFFu) == 0x7FFFu) park(bin, sh);
+    };
+    auto count_wave = [&](uint32_t key, uint32_t c) {  // one lane adds for `c` lanes that hold the same key
+        const uint32_t bin = (key ^ xor_mask) & 0xFFFFu;
+        const uint32_t sh = (bin & 1u) * 16u;
+        const uint32_t before = (atomicAdd(&cnt[bin >> 1], c << sh) >> sh) & 0xFFFFu;
+        if (before < 0x8000u && before + c >= 0x8000u) park(bin, sh);
+    };
+    // the elements ahead of the first 16-byte boundary and behind the last whole 16-byte pack: workgroup 0, one by one
+    uint64_t head = ((16u - (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15u)) & 15u) / 2u;
+    if (head > n) head = n;
+    const uint64_t npack = (n - head) / 8;
+    if (blockIdx.x == 0) {
+        if (tid < head) count(src[tid]);
+        const uint64_t t0 = head + npack * 8;
+        if (tid >= 64 && t0 + (tid - 64) < n) count(src[t0 + (tid - 64)]);
+    }
+    const uint64_t per = (npack + gridDim.x - 1) / gridDim.x;
+    const uint64_t p0 = (uint64_t)blockIdx.x * per;
+    uint64_t p1 = p0 + per;
+    if (p1 > npack) p1 = npack;
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const v4u* vsrc = reinterpret_cast<const v4u*>(src + head);
+    for (uint64_t i = p0 + tid; i < p1; i += 1024) {
+        const v4u v = __builtin_nontemporal_load(vsrc + i);
+        // skewed inputs put whole waves on one key, and same-address atomics of one instruction serialise (a constant
+        // array: 874 us per 2^28 keys): when every lane holds the first lane's 16 bytes, one lane adds for the wave
+        const uint32_t f0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[0]), f1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[1]);
+        const uint32_t f2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[2]), f3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[3]);
+        const uint64_t same = __ballot(((v[0] ^ f0) | (v[1] ^ f1) | (v[2] ^ f2) | (v[3] ^ f3)) == 0u);
+        if (same == __builtin_amdgcn_read_exec()) {
+            if (mbcnt64(same) == 0) {
+                const uint32_t c = (uint32_t)__popcll(same);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    count_wave(v[k] & 0xFFFFu, c);
+                    count_wave(v[k] >> 16, c);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                count(v[k] & 0xFFFFu);
+                count(v[k] >> 16);
+            }
+        }
+    }
+    __syncthreads();
+    uint4* out = reinterpret_cast<uint4*>(P + (size_t)blockIdx.x * 32768u);
+    for (uint32_t i = tid; i < 32768u / 4u; i += 1024u) out[i] = reinterpret_cast<const uint4*>(cnt)[i];
+}
+
+// Bin totals: grid = 256 (bins [256 j, 256 j + 256)), block = 256.  tot[bin] = overflow + sum over the count
+// kernel's workgroups; BT[j] = the block's sum.  The overflow entries are put back to zero (clean for the next sort).
+__global__ __launch_bounds__(256) void rsx_total16_kernel(const uint32_t* __restrict__ P, uint32_t parts, uint32_t* __restrict__ ovf,
+                                                          uint64_t* __restrict__ tot, uint64_t* __restrict__ BT) {
+    __shared__ uint64_t ws[4];
+    const uint32_t tid = threadIdx.x, bin = blockIdx.x * 256u + tid;
+    const uint32_t w = bin >> 1, sh = (bin & 1u) * 16u;
+    uint64_t c = ovf[bin];
+    if (c) ovf[bin] = 0;
+    for (uint32_t b0 = 0; b0 < parts; b0 += 8) {
+        uint32_t part[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) part[k] = b0 + k < parts ? P[(size_t)(b0 + k) * 32768u + w] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) c += (part[k] >> sh) & 0xFFFFu;
+    }
+    tot[bin] = c;
+    uint64_t x = c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    if ((tid & 63u) == 0u) ws[tid >> 6] = x;
+    __syncthreads();
+    if (tid == 0) BT[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// Writes the runs.  The output is cut into 1 KiB steps (64 lanes x 8 elements); a wave takes every 4th step of its
+// workgroup's contiguous share.  Two-level search: the 256 bin-block starts (scan of BT, per workgroup, in LDS) and
+// the 256 bin starts inside the block at hand (scan of its tot[], per wave, in LDS, reloaded when the wave moves on).
+// A step inside ONE bin -- n / 65536 elements on average -- is one search and a splat.
+__global__ __launch_bounds__(256) void rsx_expand16_kernel(uint16_t* __restrict__ dst, uint64_t n, const uint64_t* __restrict__ tot,
+                                                           const uint64_t* __restrict__ BT, uint32_t xor_mask) {
+    __shared__ uint64_t bt[257];        // exclusive scan of BT
+    __shared__ uint64_t st[4][257];     // per wave: bin starts of its current bin-block (absolute positions)
+    __shared__ uint64_t wsum[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    {
+        const uint64_t c = BT[tid];
+        uint64_t x = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint64_t y = __shfl_up(x, o);
+            if (lane >= (uint32_t)o) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint64_t wb = 0;
+        for (uint32_t k = 0; k < wave; ++k) wb += wsum[k];
+        bt[tid] = wb + x - c;
+        if (tid == 255) bt[256] = wb + x;
+        __syncthreads();
+    }
+    const bool wide = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
+    const uint64_t steps = (n + 511) / 512;
+    const uint64_t per = (steps + gridDim.x - 1) / gridDim.x;
+    const uint64_t s0 = (uint64_t)blockIdx.x * per;
+    uint64_t s1 = s0 + per;
+    if (s1 > steps) s1 = steps;
+    uint64_t* my = st[wave];
+    uint32_t cur = ~0u;  // bin-block whose starts `my` holds (wave-uniform)
+    auto load_block = [&](uint32_t j) {  // wave-uniform j
+        uint64_t c[4], run = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c[k] = tot[(size_t)j * 256u + lane * 4u + k];
+        const uint64_t mine = c[0] + c[1] + c[2] + c[3];
+        uint64_t x = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint64_t y = __shfl_up(x, o);
+            if (lane >= (uint32_t)o) x += y;
+        }
+        run = bt[j] + x - mine;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            my[lane * 4u + k] = run;
+            run += c[k];
+        }
+        if (lane == 63) my[256] = run;
+        cur = j;
+    };
+    auto upper = [&](const uint64_t* a, uint64_t p) -> uint32_t {  // last i in [0, 256) with a[i] <= p  (a[0] <= p given)
+        uint32_t lo = 0, hi = 256;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (a[mid] <= p) lo = mid;
+            else hi = mid;
+        }
+        return lo;
+    };
+    uint32_t jb = 0, bb = 0;  // bin-block / bin inside it that hold the wave's position: they only move forward
+    for (uint64_t s = s0 + wave; s < s1; s += 4) {
+        const uint64_t p0 = s * 512;                      // wave-uniform
+        const uint64_t pend = p0 + 512 < n ? p0 + 512 : n;
+        const uint64_t q = p0 + (uint64_t)lane * 8;       // this lane's 8 elements
+        uint32_t w[4] = {0, 0, 0, 0};
+        uint64_t done = p0;                               // positions below `done` are filled in (wave-uniform)
+        uint32_t guard = 0;
+        while (done < pend && ++guard <= 600u) {          // (a step holds at most 512 bins: bounded whatever the tables say)
+            if (cur == ~0u) {                             // first step of the wave: search; afterwards walk
+                jb = upper(bt, done);
+            } else {
+                while (jb < 255u && bt[jb + 1] <= done) ++jb;  // empty blocks are stepped over
+            }
+            if (jb != cur) {
+                load_block(jb);
+                bb = upper(my, done);
+            } else {
+                while (bb < 255u && my[bb + 1] <= done) ++bb;
+            }
+            const uint64_t lim = my[256] < pend ? my[256] : pend;  // end of what this block covers of the step
+            if (my[bb + 1] >= lim) {                      // one bin up to `lim`: splat
+                const uint32_t key = ((jb * 256u + bb) ^ xor_mask) & 0xFFFFu;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (q + k >= done && q + k < lim) w[k >> 1] |= key << (16 * (k & 1));
+            } else if (q + 8 > done && q < lim) {         // lanes with elements in [done, lim): one search, then walk
+                const uint64_t first = q > done ? q : done;
+                uint32_t bk = upper(my, first);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (q + k >= done && q + k < lim) {
+                        while (bk < 255u && my[bk + 1] <= q + k) ++bk;
+                        const uint32_t key = ((jb * 256u + bk) ^ xor_mask) & 0xFFFFu;
+                        w[k >> 1] |= key << (16 * (k & 1));
+                    }
+            }
+            done = lim;
+        }
+        if (q < n) {
+            if (wide && q + 8 <= n) {
+                *reinterpret_cast<uint4*>(dst + q) = make_uint4(w[0], w[1], w[2], w[3]);
+            } else {
+                for (int k = 0; k < 8 && q + k < n; ++k) dst[q + k] = (uint16_t)(w[k >> 1] >> (16 * (k & 1)));
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ harness --
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;

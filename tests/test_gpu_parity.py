@@ -143,6 +143,45 @@ def test_middle_size_bucket_capacity_edge(rs, torch, ctx, orc, t, over):
     assert np.array_equal(_gpu_sort(rs, torch, ctx, raw, d), orc.sort_parallel(raw, lay, 8)), (t, over)
 
 
+@pytest.mark.parametrize("t", ["u16", "i16"])
+def test_two_byte_counting_path(rs, torch, ctx, orc, t):
+    """u16 / i16 arrays of at least 2^23 elements are sorted by counting (65536 LDS counters per workgroup as 16-bit halves,
+    overflow parked in a global table, runs written from the bin totals): every distribution -- `equal` and `two` drive
+    the counters over 0x8000 --, a size that is not a multiple of the 16-byte packs, and a 2-byte-aligned start."""
+    d = _digits(rs, t)
+    lay = orc.Layout(*util.TYPES[t])
+    for i, dist in enumerate(util.DISTS):
+        n = (1 << 23) + (0 if i % 2 else 1237)
+        raw = util.make_input(t, n, dist, seed=70 + i)
+        assert np.array_equal(_gpu_sort(rs, torch, ctx, raw, d), orc.sort_parallel(raw, lay, 8)), (t, n, dist)
+    n = (1 << 23) + 5
+    raw = util.make_input(t, n, "zipf", seed=91)
+    buf = torch.zeros(2 * (n + 8), dtype=torch.uint8, device="cuda")
+    x = buf[6:6 + 2 * n]  # 2-byte aligned, not 16
+    x.copy_(torch.from_numpy(raw.copy()))
+    rs.radix_sort(x, digits=d, ctx=ctx)
+    ctx.check()
+    assert np.array_equal(x.cpu().numpy(), orc.sort_parallel(raw, lay, 8)), (t, "odd offset")
+
+
+@pytest.mark.parametrize("t,n", [("u8", 3000001), ("u16", 100003), ("u16", 5000001), ("u32", 3000001), ("u32", 300001), ("(u8,u8)", 777777)])
+def test_sort_at_odd_element_offset(rs, torch, ctx, orc, t, n):
+    """the C-ABI only asks for element alignment (the multi-GPU drivers pass interior pointers): a slice that
+    starts one element into a 16-byte aligned buffer, data and scratch alike."""
+    d = _digits(rs, t)
+    lay = orc.Layout(*util.TYPES[t])
+    es = d.elem_bytes
+    raw = util.make_input(t, n, "uniform", seed=17)
+    buf = torch.zeros(es * (n + 4), dtype=torch.uint8, device="cuda")
+    tmp = torch.zeros(es * (n + 4), dtype=torch.uint8, device="cuda")
+    x = buf[es:es * (n + 1)]
+    x.copy_(torch.from_numpy(raw.copy()))
+    rs.radix_sort(x, digits=d, ctx=ctx, tmp=tmp[es:es * (n + 1)])
+    ctx.check()
+    assert np.array_equal(x.cpu().numpy(), orc.sort_parallel(raw, lay, 8)), (t, n)
+    assert buf[:es].cpu().numpy().sum() == 0 and buf[es * (n + 1):].cpu().numpy().sum() == 0  # nothing written outside the slice
+
+
 @pytest.mark.parametrize("t", list(util.TYPES))
 @pytest.mark.parametrize("dist", util.DISTS)
 def test_distributions(rs, torch, ctx, orc, t, dist):
