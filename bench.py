@@ -33,6 +33,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 # name -> (type, log2 n per GPU, generator, param, description)
 WORKLOADS = {
+    "c1-1m-u32": ("u32", 20, "uniform", 0.0, "1M u32 uniform keys (BASELINE.json configs[0]'s size, here on the GPU: the middle-size path)"),
     "c2-256m-u32": ("u32", 28, "uniform", 0.0, "256M u32 uniform keys, 8-bit radix (BASELINE.json configs[1])"),
     "target-1b-u32": ("u32", 30, "uniform", 0.0, "1B u32 uniform keys (north-star target)"),
     "c3-1b-u64": ("u64", 30, "uniform", 0.0, "1B u64 uniform keys, 8 passes (configs[2])"),
@@ -52,7 +53,8 @@ WORKLOADS = {
     "pairs-128m-u64u64": ("(u64,u64)", 27, "uniform", 0.0, "128M (u64,u64) pairs (reference bench type, main.rs:123)"),
 }
 HEADLINE = "c3-1b-u64"  # the largest single-GPU configuration in BASELINE.json's configs (configs[2])
-EXTRA_DEFAULT = ["target-1b-u32", "c2-256m-u32", "c4-slice-512m-u32", "zipf-256m-u32", "step16-256m-u32", "zipf-256m-u64", "c5-slice-128m-pairs-zipf"]
+EXTRA_DEFAULT = ["target-1b-u32", "c2-256m-u32", "c4-slice-512m-u32", "zipf-256m-u32", "step16-256m-u32", "zipf-256m-u64", "c5-slice-128m-pairs-zipf",
+                 "c1-1m-u32", "u16-256m"]
 
 
 def digits_for(rs, t):

@@ -287,9 +287,14 @@ __global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restric
                                                        uint4* __restrict__ zero16, uint64_t zero16_n,
                                                        CleanList clean,
                                                        DigitSpec spec2 = DigitSpec{}, unsigned long long* __restrict__ J2 = nullptr) {
-    __shared__ uint32_t lh[TWO ? 2 * RADIX : RADIX];
+    // One-byte elements make 16 LDS atomics per 16-byte load, and random bins collide on the 32 banks (72 % of this
+    // kernel's LDS cycles were bank conflicts: profiles/r03_u8-256m_pmc.txt): their histogram is kept in 32 copies,
+    // copy l in bank l -- lane l of either half-wave adds to lh[bin * 32 + l % 32], so an instruction never has two
+    // lanes on one bank or one address, whatever the skew, and needs no duplicate check.
+    constexpr bool BANKED = ES == 1 && !TWO;
+    __shared__ uint32_t lh[BANKED ? 32 * RADIX : TWO ? 2 * RADIX : RADIX];
     const uint32_t tid = threadIdx.x;
-    if (tid < (TWO ? 2 * RADIX : RADIX)) lh[tid] = 0;
+    for (uint32_t i = tid; i < (BANKED ? 32u * RADIX : TWO ? 2u * RADIX : (uint32_t)RADIX); i += blockDim.x) lh[i] = 0;
     // the count matrix the first sweep accumulates into (the second pass's) is cleared here
     if (jclear != nullptr)
         for (uint32_t i = blockIdx.x * blockDim.x + tid; i < (uint32_t)J_REPL * g.num_regions * RADIX; i += gridDim.x * blockDim.x)
@@ -310,6 +315,10 @@ __global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restric
     if (end > g.n) end = g.n;
     auto count = [&](const Elem<ES>& e) {
         const uint32_t d = elem_digit<ES, FLT>(e, spec);
+        if constexpr (BANKED) {
+            atomicAdd(&lh[d * 32u + (tid & 31u)], 1u);
+            return;
+        }
         // skewed inputs put whole waves on one bin: count the wave with one atomic then
         const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
         const uint64_t same = __ballot(d == d0);
@@ -363,7 +372,13 @@ __global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restric
     }
     __syncthreads();
     if (tid < RADIX) {
-        const uint32_t c = lh[tid];
+        uint32_t c = 0;
+        if constexpr (BANKED) {
+#pragma unroll
+            for (uint32_t k = 0; k < 32; ++k) c += lh[tid * 32u + ((k + tid) & 31u)];  // thread t starts at bank t: no conflicts
+        } else {
+            c = lh[tid];
+        }
         const uint32_t bin = ((blockIdx.x % J_REPL) * g.num_regions + r) * RADIX + tid;
         if (c) {  // counters are 32 bit where a region holds < 2^32 elements (half the atomic bytes): status32()
             if (j32) atomicAdd(reinterpret_cast<uint32_t*>(J) + bin, c);
