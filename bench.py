@@ -129,7 +129,8 @@ def run_single(rs, torch, ctx, wl, steps, warmup, seed0=0x5EED0000, profile=True
         "frac_of_hbm_peak": D * 2 * n * d.elem_bytes / ms / 1e6 / HBM_PEAK_GBPS,
     }
     res["paths"] = {"rank_atomic": ctx.get_info(rs.INFO_RANK_ATOMIC), "l2_local": ctx.get_info(rs.INFO_L2_LOCAL),
-                    "static_tiles": f"{(lp >> 8) & 0xFF}/{lp & 0xFF}", "placement_verified": f"{(lp >> 16) & 0xFF}/{lp & 0xFF}"}
+                    "static_tiles": f"{(lp >> 8) & 0xFF}/{lp & 0xFF}", "placement_verified": f"{(lp >> 16) & 0xFF}/{lp & 0xFF}",
+                    "path": ["general passes", "one-launch sort", "middle-size bucket split", "one-byte counting", "two-byte counting"][(lp >> 24) & 0xF]}
     if profile and prof_tot["sweep"][1]:
         sw_ms = prof_tot["sweep"][0] / prof_tot["sweep"][1]
         res["sweep_ms_per_launch"] = sw_ms
@@ -312,7 +313,8 @@ def main():
         extra = {}
         for wl in [w for w in args.extra.split(",") if w and w != args.workload]:
             try:
-                r = run_single(rs, torch, ctx, wl, args.steps, args.warmup)
+                # (per-launch event pairs would be most of a 40 us sort: the small ones are timed without)
+                r = run_single(rs, torch, ctx, wl, args.steps, args.warmup, profile=WORKLOADS[wl][1] > 22)
                 extra[wl] = {k: r[k] for k in ("n", "type", "ms_per_sort", "gkeys_per_s", "algorithmic_gbps",
                                                "frac_of_hbm_peak") if k in r}
                 extra[wl]["sweep_gbps"] = r.get("sweep_gbps")

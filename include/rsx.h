@@ -126,7 +126,9 @@ enum {
     RSX_INFO_LAST_PASSES = 5  /* which tile schedule the passes of the context's LAST sort ran with (waits for it):
                                  bits 0-7 sweep passes launched (0: one-launch or counting path), bits 8-15 of them
                                  with static tiles (the roll call succeeded), bits 16-23 of them with the XCD
-                                 placement verified (status words of single-XCD chains stay in L2) */
+                                 placement verified (status words of single-XCD chains stay in L2), bits 24-27 the
+                                 path: 0 general passes, 1 one-launch sort of at most one tile, 2 middle-size bucket
+                                 split, 3 one-byte counting, 4 two-byte counting */
 };
 int rsx_ctx_get_info(rsx_ctx *ctx, int what, uint64_t *out);
 /* Per-launch timing with HIP events on the launch stream (measurement only).

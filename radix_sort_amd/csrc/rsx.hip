@@ -246,9 +246,12 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
     const uint32_t D = L->key_bytes;  // T::NUMBER_OF_DIGITS
     const bool counting_path = L->elem_bytes == 1 && !(ctx->options & OPT_GENERAL_BYTES);  // no sweep follows
     ctx->last_sort_passes = 0;
+    ctx->last_path = 0;
     // at most one tile: all D passes in one launch of one workgroup (rsx_small_kernel.hpp)
-    if (!counting_path && n <= (size_t)512 * kpt_for((int)L->elem_bytes) && !(ctx->options & OPT_NO_SMALL_SORT))  // one 512-thread tile
+    if (!counting_path && n <= (size_t)512 * kpt_for((int)L->elem_bytes) && !(ctx->options & OPT_NO_SMALL_SORT)) {  // one 512-thread tile
+        ctx->last_path = 1;
         return small_dispatch(ctx, d_data, n, L, st);
+    }
     // u16 / i16 arrays of at least 2^23 elements: the element is its two-byte key, so the 65536 counts ARE the sorted
     // array: count (one read), write the runs (one write) -- instead of D = 2 passes of each.  The count kernel's
     // per-workgroup counters (128 KiB each), the bin totals and the bin-block sums live in d_tmp.
@@ -285,6 +288,7 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
         hipLaunchKernelGGL(rsx_expand16_kernel, dim3((uint32_t)ctx->num_cu * 8), dim3(256), 0, st, static_cast<uint16_t*>(d_data), (uint64_t)n, tot,
                            BT, xor_mask);
         RSX_HIP(hipGetLastError());
+        ctx->last_path = 4;
         return RSX_OK;
     }
     // Middle sizes (more than one tile, up to mid_max_elems): the count kernel also counts the MOST significant digit.
@@ -315,6 +319,7 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
         if (rc) return rc;
         rc = bucket_dispatch(ctx, d_tmp, d_data, gs, L, st);    // ... sorted, they land in d_data
         if (rc) return rc;
+        ctx->last_path = 2;
         return RSX_OK;
     }
     const RegionGeom geom = make_geom(ctx, n, L->elem_bytes);
@@ -336,6 +341,7 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
                            L->key_kind == RSX_KEY_SIGNED ? 0x80u : 0u);
         RSX_HIP(hipGetLastError());
         end_control(ctx);
+        ctx->last_path = 3;
         return RSX_OK;
     }
     // pass loop with ping-pong (mod.rs:84-89); the prefix phase (mod.rs:110-120) is the prologue of each sweep
@@ -554,7 +560,7 @@ int rsx_ctx_get_info(rsx_ctx* ctx, int what, uint64_t* out) try {
         case RSX_INFO_NUM_CU: *out = (uint64_t)ctx->num_cu; return RSX_OK;
         case RSX_INFO_DEVICE: *out = (uint64_t)ctx->device; return RSX_OK;
         case RSX_INFO_LAST_PASSES: {
-            *out = 0;
+            *out = (uint64_t)ctx->last_path << 24;
             if (!ctx->aux || ctx->last_sort_passes == 0) return RSX_OK;
             if (ctx->busy) RSX_HIP(hipEventSynchronize(ctx->last_event));
             uint64_t stat = 0, placed = 0;
@@ -565,7 +571,7 @@ int rsx_ctx_get_info(rsx_ctx* ctx, int what, uint64_t* out) try {
                 stat += (mode == 1u || mode == 3u) ? 1u : 0u;
                 placed += mode == 3u ? 1u : 0u;
             }
-            *out = (uint64_t)ctx->last_sort_passes | (stat << 8) | (placed << 16);
+            *out = (uint64_t)ctx->last_sort_passes | (stat << 8) | (placed << 16) | ((uint64_t)ctx->last_path << 24);
             return RSX_OK;
         }
         default: return fail(ctx, RSX_ERR_ARG, "unknown info id");

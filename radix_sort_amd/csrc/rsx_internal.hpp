@@ -94,6 +94,7 @@ struct rsx_ctx {
     int num_cu = 256;
     uint32_t pass_index = 0;   // of the sweep being launched within its sort (selects the status half, J rotation)
     bool pass_last = true;     // no pass follows: nothing to clean
+    uint32_t last_path = 0;    // 0 general passes, 1 one-launch sort, 2 middle-size bucket split, 3 / 4 one- / two-byte counting
     uint32_t last_sort_passes = 0;  // sweep passes of the last sort (RSX_INFO_LAST_PASSES)
     rsx::CleanList clean = {{nullptr, nullptr, nullptr}, {0, 0, 0}};  // what the next count kernel zeroes on its way (the previous sort's control block)
     uint64_t cb_used[2][2] = {{0, 0}, {0, 0}};  // per alternating block: bytes of the top-digit matrix / of count matrix 0 its last sort used

@@ -18,13 +18,25 @@ for wl, (t, logn, *_r) in bench.WORKLOADS.items():
     if not os.path.exists(f):
         continue
     tot = {("sweep", "FETCH_SIZE"): [0.0, 0], ("sweep", "WRITE_SIZE"): [0.0, 0], ("hist", "FETCH_SIZE"): [0.0, 0]}
+    per_kernel = {}  # kernel -> {counter: per-dispatch KB}: the paths without a sweep (counting, middle-size split)
     for line in open(f):
         m = re.match(r".*rsx_(sweep|hist)_kernel<.*>\s+(\w+)\s+total\s+(\S+)\s+per-dispatch\s+\S+\s+dispatches\s+(\d+)", line)
         if m and (m.group(1), m.group(2)) in tot:
             tot[(m.group(1), m.group(2))][0] += float(m.group(3))
             tot[(m.group(1), m.group(2))][1] += int(m.group(4))
+        m = re.match(r".*(rsx_\w+_kernel)(?:<[^>]*>)?\s+(FETCH_SIZE|WRITE_SIZE)\s+total\s+\S+\s+per-dispatch\s+(\S+)\s+dispatches", line)
+        if m:
+            per_kernel.setdefault(m.group(1), {})[m.group(2)] = float(m.group(3))
     d = bench.digits_for(rs, t)
     n = 1 << logn
+    if not tot[("sweep", "FETCH_SIZE")][1]:  # no sweep in this path: HBM bytes of the whole sort, all its kernels
+        whole = int(round(sum(2 * k.get("FETCH_SIZE", 0.0) + k.get("WRITE_SIZE", 0.0) for k in per_kernel.values()) * 1024))
+        alg = d.key_bytes * 2 * n * d.elem_bytes
+        out[wl] = {"round": tag, "path_without_sweep_kernel": True, "kernels": sorted(per_kernel),
+                   "traffic_bytes_per_sort": whole, "algorithmic_bytes_per_sort": alg,
+                   "traffic_over_algorithmic": round(whole / alg, 4), "source": f"profiles/{tag}_{wl}_pmc.txt"}
+        print(wl, "whole sort", out[wl]["traffic_over_algorithmic"])
+        continue
     fetch = tot[("sweep", "FETCH_SIZE")][0] / tot[("sweep", "FETCH_SIZE")][1]
     write = tot[("sweep", "WRITE_SIZE")][0] / tot[("sweep", "WRITE_SIZE")][1]
     hist = tot[("hist", "FETCH_SIZE")][0] / tot[("hist", "FETCH_SIZE")][1]

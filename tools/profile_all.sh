@@ -29,7 +29,7 @@ for row in csv.DictReader(open(sys.argv[1])):
     k = row["Kernel_Name"].split("(")[0][-64:]
     acc[k][row["Counter_Name"]] += float(row["Counter_Value"]); cnt[(k, row["Counter_Name"])] += 1
 for k in sorted(acc):
-    if "sweep" in k or "hist" in k or "expand" in k or "bucket" in k or "pair" in k:
+    if any(w in k for w in ("sweep", "hist", "expand", "bucket", "tile", "count16", "total16")):
         for c, v in acc[k].items():
             print(f"{k}  {c:24s} total {v:.6g}  per-dispatch {v / cnt[(k, c)]:.6g}  dispatches {cnt[(k, c)]}")
 PY
