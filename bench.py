@@ -48,6 +48,9 @@ WORKLOADS = {
     "f64-128m": ("f64", 27, "uniform", 0.0, "128M f64 keys (uniform bit patterns)"),
     "sorted-256m-u32": ("u32", 28, "sorted", 0.0, "256M u32 keys already in order (key = index)"),
     "reversed-256m-u32": ("u32", 28, "reversed", 0.0, "256M u32 keys in reverse order"),
+    "u64-128m": ("u64", 27, "uniform", 0.0, "128M u64 uniform keys"),
+    "u64-256m": ("u64", 28, "uniform", 0.0, "256M u64 uniform keys"),
+    "u64-512m": ("u64", 29, "uniform", 0.0, "512M u64 uniform keys"),
     "u16-256m": ("u16", 28, "uniform", 0.0, "256M u16 uniform keys (2 passes)"),
     "u8-256m": ("u8", 28, "uniform", 0.0, "256M u8 uniform keys (counting path)"),
     "pairs-128m-u64u64": ("(u64,u64)", 27, "uniform", 0.0, "128M (u64,u64) pairs (reference bench type, main.rs:123)"),

@@ -216,16 +216,17 @@ constexpr uint64_t mid_max_elems(int es) { return (uint64_t)bucket_cap(es) * 256
 constexpr int kpt_for(int es) { return es <= 2 ? RSX_KPT2 : es <= 4 ? RSX_KPT4 : es == 8 ? RSX_KPT8 : es == 12 ? RSX_KPT12 : es == 16 ? RSX_KPT16 : es == 24 ? RSX_KPT24 : RSX_KPT32; }
 constexpr int wg_for(int es) { return es <= 4 ? RSX_WG4 : es == 8 ? RSX_WG8 : 512; }
 constexpr uint32_t tile_elems(int es) { return wg_for(es) * kpt_for(es); }
-// The bucket split of a middle-size sort runs the sweep with SMALL tiles (a tile is one workgroup's serial work: 13 us
-// for 14336 u32 keys, and 2^16 keys are five of those) and more, shorter chains (it counts nothing for a next pass,
-// so regions cost it no LDS and no flush): 512 x 8 4-byte, 512 x 4 8-byte, 512 x 2 16-byte elements.
+// The bucket split of a middle-size sort (rsx_mid_kernels.hpp) works on SMALL tiles, one workgroup each (a tile is one
+// workgroup's serial work: 13 us for 14336 u32 keys, and 2^16 keys are five of those): 512 x 8 4-byte, 512 x 4 8-byte,
+// 512 x 2 16-byte elements.
 constexpr int mid_kpt_for(int es) { return es <= 4 ? 8 : es == 8 ? 4 : es == 12 ? 3 : 2; }
 constexpr uint32_t mid_tile_elems(int es) { return 512u * (uint32_t)mid_kpt_for(es); }
 
 inline uint32_t log2u(uint64_t x) { return 63u - (uint32_t)__builtin_clzll(x); }
 
 // Regions: smallest power-of-two length (>= one tile) that covers n with <= cap of them.
-// small_tiles: the geometry of a middle-size sort's bucket split (mid_tile_elems, regions from 8 tiles on, up to 16).
+// small_tiles: tile count of a middle-size sort's bucket split (mid_tile_elems): only its status_rows() is used, to size
+// the workspace that holds the split's two tiles x 256 tables.
 inline RegionGeom make_geom(const rsx_ctx* ctx, uint64_t n, uint32_t es, bool small_tiles = false) {
     RegionGeom g;
     g.n = n;

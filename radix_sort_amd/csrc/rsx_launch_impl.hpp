@@ -83,11 +83,11 @@ inline KeyXform make_xform(const rsx_layout* L) {
     return x;
 }
 
-template <int ES, typename S, int XF, bool NEXT, bool MID = false, bool SMALLT = false>
+template <int ES, typename S, int XF, bool NEXT, bool MID = false>
 int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L,
                    uint32_t digit, const unsigned long long* J, unsigned long long* jnext, unsigned long long* jzero,
                    hipStream_t st) {
-    constexpr int KPT = SMALLT ? mid_kpt_for(ES) : kpt_for(ES);
+    constexpr int KPT = kpt_for(ES);
     if (g.tile != (uint32_t)(wg_for(ES) * KPT)) return fail(ctx, RSX_ERR_INTERNAL, "launch_sweep: geometry of another tile size");
     constexpr int SWEEP_WG = wg_for(ES);
     constexpr int TILE = SWEEP_WG * KPT;
@@ -203,10 +203,6 @@ template <int ES, typename S, int XF>
 int launch_sweep_n(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L,
                    uint32_t digit, const unsigned long long* J, unsigned long long* jnext, unsigned long long* jzero,
                    hipStream_t st) {
-    if constexpr ((XF & 2) == 0 && sizeof(S) == 4 && ES != 1) {  // the bucket split of a middle-size sort: small tiles
-        if (!jnext && g.tile == mid_tile_elems(ES) && mid_tile_elems(ES) != tile_elems(ES))
-            return launch_sweep_t<ES, S, XF, false, false, true>(ctx, src, dst, g, L, digit, J, nullptr, jzero, st);
-    }
     if constexpr ((XF & 2) == 0) {  // a pass that maps the keys back is a last pass: nothing to count for
         if constexpr (sizeof(S) == 4 && ES != 1) {  // the first sweep of a middle-size sort (regions of <= 2^30 elements by far)
             if (jnext && ctx->pass_mid != 0) return launch_sweep_t<ES, S, XF, true, true>(ctx, src, dst, g, L, digit, J, jnext, jzero, st);

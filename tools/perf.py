@@ -6,6 +6,7 @@ import torch
 import radix_sort_amd as rs
 import bench
 ctx = rs.default_context(0)
+if os.environ.get('MAXR'): ctx.set_option(rs.OPT_MAX_REGIONS, int(os.environ['MAXR']))
 wls = sys.argv[1:] or ["c2-256m-u32", "target-1b-u32", "zipf-256m-u64"]
 for wl in wls:
     # RSX_DEBUG only means something to a -DRSX_TUNING build (timing ablations with wrong output by design)
