@@ -187,7 +187,8 @@ int begin_control(rsx_ctx* ctx, hipStream_t st, const RegionGeom& g, bool uses_j
     const uint64_t used = (uint64_t)J_REPL * g.num_regions * RADIX * sizeof(uint64_t);  // prefix of a count matrix in use
     if (capturing(st)) {
         ctx->cb = 2;
-        RSX_HIP(hipMemsetAsync(cb_of(ctx, 2), 0, CB_BYTES, st));
+        hipLaunchKernelGGL(rsx_zero16_kernel, dim3(64), dim3(256), 0, st, reinterpret_cast<uint4*>(cb_of(ctx, 2)), (uint64_t)(CB_BYTES / 16));
+        RSX_HIP(hipGetLastError());
         return RSX_OK;
     }
     if (ctx->cb_dirty) {

@@ -24,6 +24,13 @@ __global__ __launch_bounds__(256) void rsx_totals_kernel(const unsigned long lon
     counts_out[tid] = c;
 }
 
+// Zeroes n16 x 16 bytes (a control block, by sorts that are being captured into a graph: a 788 KiB memset NODE aborted
+// at replay on ROCm 7.2, a kernel node does not).
+__global__ __launch_bounds__(256) void rsx_zero16_kernel(uint4* __restrict__ p, uint64_t n16) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x)
+        p[i] = make_uint4(0, 0, 0, 0);
+}
+
 // ------------------------------------------------------------ one-byte elements --
 // An element that IS its one-byte key (u8, i8) is fully described by its digit: the sorted array is
 // the 256 counts written out as runs (counting sort: one read of the data, one write, no scatter).

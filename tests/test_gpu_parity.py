@@ -520,6 +520,46 @@ def test_many_sorts_one_context_and_graph_capture(rs, torch, ctx):
     assert torch.equal(work.cpu(), torch.sort(src.cpu()).values)
 
 
+@pytest.mark.parametrize("n", [300001, 5000001])
+def test_graph_replay_with_changing_inputs(rs, torch, orc, n):
+    """A captured sort is replayed on different inputs: the middle-size path is captured as the bucket split (the
+    forecast is taken at capture time) and a replay on a skewed input must still be right (oversized buckets through
+    memory); the general path under capture uses the control block that it zeroes itself, replay after replay."""
+    c = rs.Context(torch.cuda.current_device())
+    d = rs.PRIMITIVES["u32"]
+    lay = orc.Layout(*util.TYPES["u32"])
+    c.reserve(n, d)
+    inputs = [util.make_input("u32", n, dist, seed=40 + i) for i, dist in enumerate(("uniform", "zipf", "uniform", "equal", "sorted"))]
+    src = torch.from_numpy(inputs[0].copy()).cuda()
+    work, tmp = torch.empty_like(src), torch.empty_like(src)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        work.copy_(src)
+        c.sort_device(work.data_ptr(), tmp.data_ptr(), n, d, s.cuda_stream)  # warm-up outside capture (and the forecast's first report)
+    s.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        work.copy_(src)
+        c.sort_device(work.data_ptr(), tmp.data_ptr(), n, d, torch.cuda.current_stream().cuda_stream)
+    for raw in inputs:
+        src.copy_(torch.from_numpy(raw.copy()))
+        graph.replay()
+        torch.cuda.synchronize()
+        c.check()
+        assert np.array_equal(work.cpu().numpy(), orc.sort_parallel(raw, lay, 8))
+    # an uncaptured sort between replays, then a replay again (the alternating control blocks are not the graph's)
+    y = torch.from_numpy(inputs[1].copy()).cuda()
+    rs.radix_sort(y, digits=d, ctx=c)
+    c.check()
+    assert np.array_equal(y.cpu().numpy(), orc.sort_parallel(inputs[1], lay, 8))
+    src.copy_(torch.from_numpy(inputs[2].copy()))
+    graph.replay()
+    torch.cuda.synchronize()
+    c.check()
+    assert np.array_equal(work.cpu().numpy(), orc.sort_parallel(inputs[2], lay, 8))
+    c.close()
+
+
 # ---- rsx_sort_sharded: single-process multi-slice sort (slices share the one GPU of the test box) ----
 SHARD_SPLITS = [
     [5000, 5000], [1, 9999], [0, 7000, 3000], [3333, 0, 3333, 3334], [12345], [100003, 50001, 70007],
