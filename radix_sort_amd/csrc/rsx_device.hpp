@@ -531,6 +531,9 @@ constexpr uint32_t SWEEP_OPT_PREREAD = 16u;      // 4-byte and narrower elements
 #ifndef RSX_LB_EVERY
 #define RSX_LB_EVERY 4    // elements a wave reorders between two look-back steps
 #endif
+#ifndef RSX_HOT_MBCNT
+#define RSX_HOT_MBCNT 1  // dominant-digit ranks: the running count rides in v_mbcnt's addend
+#endif
 #ifndef RSX_PREFETCH_ALL
 #define RSX_PREFETCH_ALL 3  // 0 off, 1 before/after the look-back, 2 behind it, 3 = 2 where measured faster (>= 12-byte elements)
 #endif
@@ -1104,10 +1107,20 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                         // is still returning into, and every round waits for its LDS atomic (s_waitcnt lgkmcnt(0)
                         // per round).  Zipf u32 -1.7 %; 8-byte elements measured 2 % slower this way, so they keep
                         // the branch.
+#if RSX_HOT_MBCNT
+                        // ... and that hot value is already the lane's rank: v_mbcnt takes an addend, so
+                        // hot_run + (hot lanes below me) is two VALU with the running count as the addend -- no select, no
+                        // separate `below` (the other lanes' atomic return overwrites it)
+                        uint32_t w = __builtin_amdgcn_mbcnt_hi((uint32_t)(h >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)h, hot_run)) << sh[r];
+                        if (d != hotd) w = atomicAdd(&my_hist2[WIDE_CNT ? d : (d >> 1)], 1u << sh[r]);
+                        word[r] = w;
+                        below[r] = 0u;
+#else
                         uint32_t w = hot_run << sh[r];
                         if (d != hotd) w = atomicAdd(&my_hist2[WIDE_CNT ? d : (d >> 1)], 1u << sh[r]);
                         word[r] = w;
                         below[r] = d == hotd ? mbcnt64(h) : 0u;
+#endif
                     } else if (d == hotd) {
                         below[r] = mbcnt64(h);
                         word[r] = hot_run << sh[r];
