@@ -1392,7 +1392,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                                         same = __ballot(bin == hot_bin);
                                     }
                                 }
-                                hot_acc += (uint32_t)__popcll(same);
+                                hot_acc += (uint32_t)__popcll(same);  // (a per-LANE counter summed at the flushes: Zipf u32 +3.5 %, step-16 +2.6 %)
                                 if (bin != hot_bin) atomicAdd(&s_jn[bin], 1u);
                             } else if (!RSX_DBG(a, 0x8u)) {
                                 atomicAdd(&s_jn[next_bin(idx, x)], 1u);  // (0x8: ablation, no next-pass count)
