@@ -237,8 +237,11 @@ __device__ void big_bucket_sort(const SmallArgs& a, Elem<ES>* buf0, Elem<ES>* bu
         E* t = src;
         src = dst;
         dst = t;
-        __threadfence_block();
+        // the next pass reads, through this CU's vector L1, what this pass wrote (and two passes on, addresses that
+        // were read before they were rewritten): write back, meet, and drop what the L1 holds
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
 }
 

@@ -122,6 +122,44 @@ def test_middle_size_forecast_and_oversized_buckets(rs, torch, orc, t):
     c.close()
 
 
+@pytest.mark.parametrize("t,extra", [("u32", 1), ("u32", 200), ("u64", 50), ("(u32,u32)", 3), ("f32", 1000)])
+def test_small_bucket_workgroups_meet_an_oversized_bucket(rs, torch, orc, t, extra):
+    """After a uniform input the forecast picks 256-thread bucket workgroups (every bucket fitted a quarter of the large
+    capacity).  The next input holds ONE bucket just over that small capacity: its workgroup sorts it through memory in
+    D-1 passes, and the bucket is small enough to stay in the CU's vector L1 from pass to pass -- the passes must not
+    read stale lines."""
+    d = _digits(rs, t)
+    es, ko, kb, _kind = util.TYPES[t]
+    lay = orc.Layout(*util.TYPES[t])
+    c = rs.Context(torch.cuda.current_device())
+    n = 200000
+    raw = util.make_input(t, n, "uniform", seed=7)
+    x = torch.from_numpy(raw.copy()).cuda()
+    rs.radix_sort(x, digits=d, ctx=c)
+    c.check()
+    assert np.array_equal(x.cpu().numpy(), orc.sort_parallel(raw, lay, 8))
+    cap_small = 256 * BUCKET_KEYS[es]
+    for rep in range(3):
+        raw = util.make_input(t, n, "uniform", seed=8 + rep).reshape(n, es)
+        rng = np.random.default_rng(9 + rep)
+        top = raw[:, ko + kb - 1]
+        top[top == 0x33] = 0x34
+        top[rng.choice(n, size=cap_small + extra, replace=False)] = 0x33  # one bucket just over the small capacity
+        raw = raw.reshape(-1)
+        x = torch.from_numpy(raw.copy()).cuda()
+        rs.radix_sort(x, digits=d, ctx=c)
+        c.check()
+        assert np.array_equal(x.cpu().numpy(), orc.sort_parallel(raw, lay, 8)), (t, extra, rep)
+        # back to uniform so that the forecast returns to the small workgroups for the next repetition
+        for k in range(10):
+            u = util.make_input(t, n, "uniform", seed=100 + 10 * rep + k)
+            y = torch.from_numpy(u.copy()).cuda()
+            rs.radix_sort(y, digits=d, ctx=c)
+            c.check()
+            assert np.array_equal(y.cpu().numpy(), orc.sort_parallel(u, lay, 8))
+    c.close()
+
+
 @pytest.mark.parametrize("t", ["u32", "(u64,u64)", "i16", "f64"])
 @pytest.mark.parametrize("over", [0, 1])
 def test_middle_size_bucket_capacity_edge(rs, torch, ctx, orc, t, over):
