@@ -206,13 +206,16 @@ struct LaunchTimer {
 #ifndef RSX_WG8
 #define RSX_WG8 512
 #endif
-// rsx_bucket_sort_kernel: 1024 threads x BKPT elements in registers, the bucket in LDS (<= 112 KiB) beside 16 KiB of
-// wave counters
-constexpr int bucket_kpt_for(int es) { return es <= 4 ? 28 : es == 8 ? 14 : es == 12 ? 9 : es == 16 ? 7 : es == 24 ? 4 : 3; }
+// rsx_bucket_sort_kernel: 1024 threads x BKPT elements in registers, the bucket in LDS (<= 112 KiB, 8-byte elements
+// 136 KiB) beside 16 KiB of wave counters
+constexpr int bucket_kpt_for(int es) { return es <= 4 ? 28 : es == 8 ? 17 : es == 12 ? 9 : es == 16 ? 7 : es == 24 ? 4 : 3; }
 constexpr uint32_t bucket_cap(int es) { return 1024u * (uint32_t)bucket_kpt_for(es); }
 // Largest array taken by the middle-size path: the average bucket is 4/7 of the capacity, so uniform top digits
-// pass with a wide margin (2^22 4-byte, 2^21 8-byte, 2^20 16-byte elements); skewed ones fall back to LSD passes.
-constexpr uint64_t mid_max_elems(int es) { return (uint64_t)bucket_cap(es) * 256u * 4u / 7u; }
+// pass with a wide margin (2^22 4-byte, 2^20 16-byte elements); skewed ones fall back to LSD passes.  8-byte elements
+// go up to 2^22 as well (the general path needs 275 us there, this one 90): the average bucket is then 16384 of 17408,
+// eight standard deviations of a uniform top digit below the capacity; a bucket that overflows all the same is sorted
+// through memory by its workgroup, which costs about what the general path would have.
+constexpr uint64_t mid_max_elems(int es) { return es == 8 ? (1ull << 22) : (uint64_t)bucket_cap(es) * 256u * 4u / 7u; }
 constexpr int kpt_for(int es) { return es <= 2 ? RSX_KPT2 : es <= 4 ? RSX_KPT4 : es == 8 ? RSX_KPT8 : es == 12 ? RSX_KPT12 : es == 16 ? RSX_KPT16 : es == 24 ? RSX_KPT24 : RSX_KPT32; }
 constexpr int wg_for(int es) { return es <= 4 ? RSX_WG4 : es == 8 ? RSX_WG8 : 512; }
 constexpr uint32_t tile_elems(int es) { return wg_for(es) * kpt_for(es); }

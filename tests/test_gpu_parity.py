@@ -71,11 +71,11 @@ def test_sizes_around_the_tile(rs, torch, ctx, orc, t):
         assert np.array_equal(_gpu_sort(rs, torch, ctx, raw, d), orc.sort_parallel(raw, lay, 3)), (t, n, dist)
 
 
-BUCKET_KEYS = {2: 28, 4: 28, 8: 14, 12: 9, 16: 7, 24: 4, 32: 3}  # keys per thread of the 1024-thread bucket kernel, by element size
+BUCKET_KEYS = {2: 28, 4: 28, 8: 17, 12: 9, 16: 7, 24: 4, 32: 3}  # keys per thread of the 1024-thread bucket kernel, by element size
 
 
 def _mid_max(es):
-    return 1024 * BUCKET_KEYS[es] * 256 * 4 // 7
+    return 1 << 22 if es == 8 else 1024 * BUCKET_KEYS[es] * 256 * 4 // 7
 
 
 @pytest.mark.parametrize("t", [t for t in util.TYPES if util.TYPES[t][2] >= 2])
