@@ -60,6 +60,10 @@ EXTRA_DEFAULT = ["target-1b-u32", "c2-256m-u32", "c4-slice-512m-u32", "zipf-256m
                  "c1-1m-u32", "u16-256m"]
 
 
+PATH_NAMES = ["general passes", "one-launch sort", "middle-size bucket split", "one-byte counting", "two-byte counting",
+              "wide-key hybrid (top 16 bits by two sweeps, the other digits in LDS)"] + ["?"] * 10
+
+
 def digits_for(rs, t):
     if t.startswith("("):
         k, p = t[1:-1].split(",")
@@ -93,7 +97,7 @@ def run_single(rs, torch, ctx, wl, steps, warmup, seed0=0x5EED0000, profile=True
         ctx.sort_device(bufs[0].data_ptr(), tmp.data_ptr(), n, d, stream)
     done = 0
     total_ms = 0.0
-    prof_tot = {"sweep": [0.0, 0], "hist": [0.0, 0]}
+    prof_tot = {"sweep": [0.0, 0], "hist": [0.0, 0], "scan": [0.0, 0], "other": [0.0, 0]}
     while done < steps:  # pool-sized rounds (pool == steps unless memory is short)
         k = min(pool, steps - done)
         for i in range(k):
@@ -131,16 +135,29 @@ def run_single(rs, torch, ctx, wl, steps, warmup, seed0=0x5EED0000, profile=True
         "algorithmic_gbps": D * 2 * n * d.elem_bytes / ms / 1e6,
         "frac_of_hbm_peak": D * 2 * n * d.elem_bytes / ms / 1e6 / HBM_PEAK_GBPS,
     }
+    path = (lp >> 24) & 0xF
     res["paths"] = {"rank_atomic": ctx.get_info(rs.INFO_RANK_ATOMIC), "l2_local": ctx.get_info(rs.INFO_L2_LOCAL),
                     "static_tiles": f"{(lp >> 8) & 0xFF}/{lp & 0xFF}", "placement_verified": f"{(lp >> 16) & 0xFF}/{lp & 0xFF}",
-                    "path": ["general passes", "one-launch sort", "middle-size bucket split", "one-byte counting", "two-byte counting"][(lp >> 24) & 0xF]}
+                    "path": PATH_NAMES[path]}
     if profile and prof_tot["sweep"][1]:
-        sw_ms = prof_tot["sweep"][0] / prof_tot["sweep"][1]
+        # wide-key hybrid: both kernel sequences are enqueued and the device runs one (the other's launches return at
+        # once, ~5 us each, and are inside these sums): per sort 2 real sweeps, 1 bucket kernel, 1 count + 1 marginal
+        real = 2 * steps if path == 5 else prof_tot["sweep"][1]
+        sw_ms = prof_tot["sweep"][0] / real
         res["sweep_ms_per_launch"] = sw_ms
-        res["sweep_launches"] = prof_tot["sweep"][1]
+        res["sweep_launches"] = real
         res["sweep_gbps"] = 2 * n * d.elem_bytes / sw_ms / 1e6
         if prof_tot["hist"][1]:
-            res["hist_ms_per_launch"] = prof_tot["hist"][0] / prof_tot["hist"][1]
+            res["hist_ms_per_launch"] = prof_tot["hist"][0] / (steps if path == 5 else prof_tot["hist"][1])
+        if path == 5 and prof_tot["other"][1]:
+            bk_ms = prof_tot["other"][0] / steps
+            res["bucket_ms_per_launch"] = bk_ms
+            res["bucket_launches"] = steps
+            res["bucket_passes"] = D - 2
+            res["bucket_algorithmic_gbps"] = (D - 2) * 2 * n * d.elem_bytes / bk_ms / 1e6
+            res["bucket_hbm_gbps"] = 2 * n * d.elem_bytes / bk_ms / 1e6
+            res["count16_ms_per_sort"] = prof_tot["hist"][0] / steps
+            res["scan16_ms_per_sort"] = prof_tot["scan"][0] / steps
     return res
 
 
@@ -219,12 +236,49 @@ def cpu_ladder(logn=24, t_name="(u32,u32)", runs=3):
     return {"sample": f"{n} {t_name} uniform keys, mean of {runs} runs", "cores": cores, "kind": "port", "rungs": rungs}
 
 
-def pmc_traffic(workload):
+def roofline_of(res, workload, n, d):
+    """The `roofline` object of the JSON line: the dominant kernel of the sort that ran.  General passes: rsx_sweep_kernel
+    (one launch = one digit pass, 2*n*s algorithmic bytes).  Wide-key hybrid: rsx_bucket16_kernel -- one launch does
+    D-2 of the algorithm's digit passes, so its algorithmic bytes are (D-2)*2*n*s (SURVEY.md 8(d): 2*n*s per pass);
+    those passes run in LDS, the kernel's own HBM traffic is 2*n*s, and both rates are given."""
+    sweep = {
+        "bound": "hbm", "kernel": "rsx_sweep_kernel (one launch = one digit pass)",
+        "achieved": res.get("sweep_gbps"), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": (res.get("sweep_gbps") or 0.0) / HBM_PEAK_GBPS,
+        "algorithmic_bytes_per_launch": 2 * n * d.elem_bytes,
+        "avg_launch_ms": res.get("sweep_ms_per_launch"), "launches_timed": res.get("sweep_launches"),
+        "traffic": pmc_traffic(workload),
+        "traffic_note": "HBM bytes per launch, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, separate passes), profiles/pmc_traffic.json",
+    }
+    if "bucket_ms_per_launch" not in res:
+        return sweep
+    D = d.key_bytes
+    return {
+        "bound": "hbm", "kernel": f"rsx_bucket16_kernel (one launch = {D - 2} digit passes of every 16-bit bucket, in LDS)",
+        "achieved": res["bucket_algorithmic_gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": res["bucket_algorithmic_gbps"] / HBM_PEAK_GBPS,
+        "algorithmic_bytes_per_launch": (D - 2) * 2 * n * d.elem_bytes,
+        "avg_launch_ms": res["bucket_ms_per_launch"], "launches_timed": res["bucket_launches"],
+        "hbm_bytes_per_launch_by_design": 2 * n * d.elem_bytes,
+        "hbm_gbps_by_design": res["bucket_hbm_gbps"], "hbm_frac_by_design": res["bucket_hbm_gbps"] / HBM_PEAK_GBPS,
+        "traffic": pmc_traffic(workload, "bucket16"),
+        "note": "frac counts the algorithm's bytes for the digit passes this launch performs; it can exceed 1 because they "
+                "run in LDS (the kernel reads and writes the array once: hbm_*_by_design, traffic = rocprofv3 PMC)",
+        "per_sort_ms": {"count16 + marginal": res.get("count16_ms_per_sort"), "total16 + scan16": res.get("scan16_ms_per_sort"),
+                        "sweeps (2)": 2 * res["sweep_ms_per_launch"], "bucket16": res["bucket_ms_per_launch"]},
+        "sweep": sweep,
+    }
+
+
+def pmc_traffic(workload, kernel="sweep"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/pmc_traffic.json; bench.py cannot run the profiler on itself)."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f).get(workload, {}).get("traffic_bytes_per_launch")
+            e = json.load(f).get(workload, {})
+            if kernel != "sweep":
+                e = e.get(kernel, {})
+            return e.get("traffic_bytes_per_launch")
     except (OSError, ValueError):
         return None
 
@@ -302,15 +356,7 @@ def main():
                        "algorithmic_bytes_per_sort": d.key_bytes * 2 * n * d.elem_bytes,
                        "whole_sort_algorithmic_gbps": res["algorithmic_gbps"],
                        "whole_sort_frac_of_hbm_peak": res["frac_of_hbm_peak"]},
-            "roofline": {
-                "bound": "hbm", "kernel": "rsx_sweep_kernel (one launch = one digit pass)",
-                "achieved": res.get("sweep_gbps"), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": (res.get("sweep_gbps") or 0.0) / HBM_PEAK_GBPS,
-                "algorithmic_bytes_per_launch": 2 * n * d.elem_bytes,
-                "avg_launch_ms": res.get("sweep_ms_per_launch"), "launches_timed": res.get("sweep_launches"),
-                "traffic": pmc_traffic(args.workload),
-                "traffic_note": "HBM bytes per launch, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, separate passes), profiles/pmc_traffic.json",
-            },
+            "roofline": roofline_of(res, args.workload, n, d),
             "paths": res["paths"],
         }
         extra = {}

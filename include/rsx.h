@@ -115,7 +115,12 @@ enum {
                                   the host forecasts from what the context's previous middle-size sort reported; an input
                                   that is skewed after all is still sorted correctly (an oversized bucket goes through
                                   memory), then the context keeps to LSD passes for its next sorts.  0: LSD passes always,
-                                  top digit not even counted.  2: always split.  3: always LSD passes. */
+                                  top digit not even counted.  2: always split.  3: always LSD passes. */,
+    RSX_OPT_WIDE_SORT = 12     /* large arrays of 8-byte (and wider) keys: count the top 16 bits of the key, two sweeps for
+                                  those two digits, then every 16-bit bucket sorted by its remaining digits in LDS.
+                                  0: never; 1 (default): arrays of 2 GiB and more, when the count says every bucket
+                                  fits; 2: always (any array of 65536+ such elements, buckets that do not fit go through
+                                  memory); 3: as 1 without the size floor (above the middle sizes) */
 };
 int rsx_ctx_set_option(rsx_ctx *ctx, int option, uint64_t value);
 enum {
@@ -128,7 +133,8 @@ enum {
                                  with static tiles (the roll call succeeded), bits 16-23 of them with the XCD
                                  placement verified (status words of single-XCD chains stay in L2), bits 24-27 the
                                  path: 0 general passes, 1 one-launch sort of at most one tile, 2 middle-size bucket
-                                 split, 3 one-byte counting, 4 two-byte counting */
+                                 split, 3 one-byte counting, 4 two-byte counting, 5 wide-key hybrid (two sweeps + the
+                                 16-bit buckets in LDS; a hybrid the device refused reports 0 and its D passes) */
 };
 int rsx_ctx_get_info(rsx_ctx *ctx, int what, uint64_t *out);
 /* Per-launch timing with HIP events on the launch stream (measurement only).

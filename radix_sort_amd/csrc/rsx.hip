@@ -60,6 +60,16 @@ struct Enqueue {
     }
 };
 
+uint32_t bucket_cap_for(uint32_t es) {
+    switch (es) {
+        case 8: return bucket_cap(8);
+        case 12: return bucket_cap(12);
+        case 16: return bucket_cap(16);
+        case 24: return bucket_cap(24);
+        case 32: return bucket_cap(32);
+        default: return bucket_cap(4);
+    }
+}
 uint64_t mid_max_for(uint32_t es) {
     switch (es) {
         case 2: return mid_max_elems(2);
@@ -161,6 +171,17 @@ int mid_split_dispatch(rsx_ctx* ctx, const void* src, void* dst, size_t n, const
 int bucket_dispatch(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L, hipStream_t st) {
     RSX_DISPATCH_ES(L->elem_bytes, launch_bucket_sort, ctx, src, dst, g, L, st)
 }
+int count16top_dispatch(rsx_ctx* ctx, const void* src, size_t n, const rsx_layout* L, uint32_t* P, uint32_t parts, uint32_t region_shift,
+                        uint32_t k, hipStream_t st) {
+    RSX_DISPATCH_ES(L->elem_bytes, launch_count16top, ctx, src, n, L, P, parts, region_shift, k, st)
+}
+int marginal16_dispatch(rsx_ctx* ctx, const uint32_t* P, uint32_t parts, uint32_t k, const RegionGeom& g, const rsx_layout* L,
+                        unsigned long long* J, unsigned long long* jclear, hipStream_t st) {
+    RSX_DISPATCH_ES(L->elem_bytes, launch_marginal16, ctx, P, parts, k, g, J, jclear, st)
+}
+int bucket16_dispatch(rsx_ctx* ctx, void* data, void* scratch, size_t n, const rsx_layout* L, const uint64_t* starts, hipStream_t st) {
+    RSX_DISPATCH_ES(L->elem_bytes, launch_bucket16, ctx, data, scratch, n, L, starts, st)
+}
 int small_dispatch(rsx_ctx* ctx, void* data, size_t n, const rsx_layout* L, hipStream_t st) {
     RSX_DISPATCH_ES(L->elem_bytes, launch_small_sort, ctx, data, n, L, st)
 }
@@ -237,6 +258,36 @@ int pending_error(rsx_ctx* ctx) {
     return RSX_OK;
 }
 
+// The D LSD passes of mod.rs:84-169 on the device: count phase of pass 0 (later passes are counted by the sweep before
+// them), then D sweeps with ping-pong; the prefix phase (mod.rs:110-120) is the prologue of each sweep.  mid: a
+// middle-size sort whose first sweep also reports what the top digit looks like (mid_mode 2).
+int lsd_passes(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const rsx_layout* L, const RegionGeom& geom, bool mid, uint32_t mid_mode,
+               hipStream_t st) {
+    const uint32_t D = L->key_bytes;
+    int rc;
+    if (mid) rc = hist2_dispatch(ctx, d_data, geom, L, 0, J_of(ctx, 0), D - 1, JT_of(ctx), J_of(ctx, 1), st);
+    else rc = hist_dispatch(ctx, d_data, geom, L, 0, J_of(ctx, 0), D > 1 ? J_of(ctx, 1) : nullptr, true, st);
+    if (rc) return rc;
+    ctx->last_sort_passes = D;
+    ctx->cb_last = ctx->cb;
+    for (uint32_t d = 0; d < D; ++d) {
+        const void* src = (d % 2 == 0) ? d_data : d_tmp;
+        void* dst = (d % 2 == 0) ? d_tmp : d_data;
+        unsigned long long* jnext = (d + 1 < D) ? J_of(ctx, (d + 1) % 3) : nullptr;
+        unsigned long long* jzero = (d + 2 < D) ? J_of(ctx, (d + 2) % 3) : nullptr;
+        const int xf = (d == 0 ? 1 : 0) | (d + 1 == D ? 2 : 0);  // key map on at the first, off at the last pass
+        ctx->pass_index = d;
+        ctx->pass_last = d + 1 == D;
+        ctx->pass_mid = d == 0 ? mid_mode : 0u;  // (2: the first LSD pass also reports whether the top digit's buckets would fit)
+        rc = sweep_dispatch(ctx, src, dst, geom, L, d, J_of(ctx, d % 3), jnext, jzero, xf, st);  // mod.rs:121-168
+        ctx->pass_mid = 0;
+        if (rc) return rc;
+    }
+    if (D % 2 == 1)  // odd-D copy-back (mod.rs:170-174)
+        RSX_HIP(hipMemcpyAsync(d_data, d_tmp, n * (size_t)L->elem_bytes, hipMemcpyDeviceToDevice, st));
+    return RSX_OK;
+}
+
 // body of rsx_sort_device; caller holds ctx->mu and has set the device
 int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const rsx_layout* L, hipStream_t st) {
     int rc = pending_error(ctx);
@@ -292,6 +343,92 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
         ctx->last_path = 4;
         return RSX_OK;
     }
+    // Wide keys, large arrays (rsx_mid_kernels.hpp): two passes through memory for the top 16 bits, the rest in LDS --
+    // when the count of those 16 bits says that every bucket fits a workgroup.  That is known on the device only, so
+    // BOTH kernel sequences are enqueued, gated on the verdict word rsx_scan16_kernel writes (a launch that returns at
+    // once costs ~5 us: nothing beside milliseconds).  A refused try costs its count (one read of the array): the
+    // verdict is also written host-visibly, and after a refusal the context goes 15 sorts without trying.
+    const uint32_t es = L->elem_bytes;
+    const bool wide_type = ctx->wide_mode >= 2 ? (es >= 4 && D >= 4) : (es >= 8 && D >= 8);
+    const bool wide_size = wide_type && (uint64_t)n > mid_max_for(es);
+    bool wide = false;
+    if (ctx->wide_mode == 2) {
+        wide = wide_type && n >= 65536;
+    } else if (((ctx->wide_mode == 1 && n * (size_t)es >= ((size_t)2 << 30)) || ctx->wide_mode == 3) && wide_size &&
+               (uint64_t)n / 65536u < (uint64_t)bucket_cap_for(es)) {  // (the real test is the device's, on the actual counts)
+        volatile uint32_t* hint = reinterpret_cast<volatile uint32_t*>(ctx->host_err) + 9;  // the last try's verdict: 1 taken, 2 refused
+        if (ctx->wide_skip > 0) {
+            --ctx->wide_skip;
+        } else if (*hint == 2u) {
+            *hint = 0;
+            ctx->wide_skip = 15;
+        } else {
+            wide = true;
+        }
+    }
+    if (wide && (ctx->ovf16 == nullptr || ctx->wide_buf == nullptr) && capturing(st)) wide = false;
+    if (wide) {
+        if (!ctx->ovf16) {
+            RSX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->ovf16), 65536 * sizeof(uint32_t)));
+            RSX_HIP(hipMemsetAsync(ctx->ovf16, 0, 65536 * sizeof(uint32_t), st));
+        }
+        if (!ctx->wide_buf) RSX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->wide_buf), (65536 + 256 + 65537 + 1) * sizeof(uint64_t)));
+        uint64_t* tot = reinterpret_cast<uint64_t*>(ctx->wide_buf);
+        uint64_t* BT = tot + 65536;
+        uint64_t* starts = BT + 256;
+        uint32_t* verdict = reinterpret_cast<uint32_t*>(starts + 65537);
+        const RegionGeom geom = make_geom(ctx, n, es);
+        // the count's workgroups: k per region of the sweeps' geometry where the scratch array holds their counters
+        // (128 KiB each) -- then the first sweep's count matrix is a marginal of those counters -- and no counter can
+        // overflow when the hybrid is taken (the device's verdict: every bucket fits LDS, so fewer than 0x8000 elements);
+        // else flat shares, and a count kernel of its own for that sweep
+        size_t parts = n * (size_t)es / (32768 * sizeof(uint32_t));
+        if (parts > (size_t)ctx->num_cu) parts = (size_t)ctx->num_cu;
+        static_assert(bucket_cap(8) < 0x8000u, "a bucket that fits LDS must not overflow a 16-bit counter");
+        uint32_t k = ctx->wide_mode == 2 ? 0u : (uint32_t)(parts / geom.num_regions);
+        if (k > 0) parts = (size_t)k * geom.num_regions;
+        rc = count16top_dispatch(ctx, d_data, n, L, static_cast<uint32_t*>(d_tmp), (uint32_t)parts, geom.region_shift, k, st);  // partial counts in d_tmp
+        if (rc) return rc;
+        {
+            LaunchTimer lt(ctx, RSX_PROF_SCAN, st);
+            hipLaunchKernelGGL(rsx_total16_kernel, dim3(256), dim3(256), 0, st, static_cast<const uint32_t*>(d_tmp), (uint32_t)parts, ctx->ovf16, tot, BT);
+            RSX_HIP(hipGetLastError());
+            hipLaunchKernelGGL(rsx_scan16_kernel, dim3(1), dim3(1024), 0, st, tot, starts,
+                               ctx->wide_mode == 2 ? ~0ull : (uint64_t)bucket_cap_for(es), verdict, ctx->host_err_dev + 9);
+            RSX_HIP(hipGetLastError());
+        }
+        rc = begin_control(ctx, st, geom, false);
+        if (rc) return rc;
+        const CleanList clean = ctx->clean;  // whichever count kernel runs does the cleaning
+        ctx->cb_last = ctx->cb;
+        // sequence 1 (verdict 1): LSD passes on digits D-2 and D-1, then every 16-bit bucket in LDS
+        ctx->gate = Gate{verdict, 1u};
+        if (k > 0) rc = marginal16_dispatch(ctx, static_cast<const uint32_t*>(d_tmp), (uint32_t)parts, k, geom, L, J_of(ctx, 0), J_of(ctx, 1), st);
+        else rc = hist_dispatch(ctx, d_data, geom, L, D - 2, J_of(ctx, 0), J_of(ctx, 1), true, st);
+        if (rc == RSX_OK) {
+            ctx->pass_index = 0;
+            ctx->pass_last = false;
+            rc = sweep_dispatch(ctx, d_data, d_tmp, geom, L, D - 2, J_of(ctx, 0), J_of(ctx, 1), nullptr, 1, st);  // keys mapped on load
+        }
+        if (rc == RSX_OK) {
+            ctx->pass_index = 1;
+            ctx->pass_last = true;
+            rc = sweep_dispatch(ctx, d_tmp, d_data, geom, L, D - 1, J_of(ctx, 1), nullptr, nullptr, 0, st);  // ... and stay mapped
+        }
+        if (rc == RSX_OK) rc = bucket16_dispatch(ctx, d_data, d_tmp, n, L, starts, st);
+        // sequence 2 (verdict 2): the D LSD passes
+        if (rc == RSX_OK) {
+            ctx->gate = Gate{verdict, 2u};
+            ctx->clean = clean;
+            rc = lsd_passes(ctx, d_data, d_tmp, n, L, geom, false, 0, st);
+        }
+        ctx->gate = Gate{nullptr, 0u};
+        if (rc) return rc;
+        ctx->last_sort_passes = D;
+        ctx->last_path = 5;
+        end_control(ctx);
+        return RSX_OK;
+    }
     // Middle sizes (more than one tile, up to mid_max_elems): the count kernel also counts the MOST significant digit.
     // If that digit spreads the array over its 256 buckets so that each fits a workgroup's LDS, one sweep makes the
     // buckets and rsx_bucket_sort_kernel sorts each by the remaining digits: 4 launches and two trips through memory
@@ -326,9 +463,14 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
     const RegionGeom geom = make_geom(ctx, n, L->elem_bytes);
     rc = begin_control(ctx, st, geom, mid);
     if (rc) return rc;
-    // count phase of pass 0 (mod.rs:90-109); later passes are counted by the sweep before them
-    if (mid) rc = hist2_dispatch(ctx, d_data, geom, L, 0, J_of(ctx, 0), D - 1, JT_of(ctx), J_of(ctx, 1), st);
-    else rc = hist_dispatch(ctx, d_data, geom, L, 0, J_of(ctx, 0), D > 1 ? J_of(ctx, 1) : nullptr, !counting_path, st);
+    if (!counting_path) {
+        rc = lsd_passes(ctx, d_data, d_tmp, n, L, geom, mid, mid_mode, st);
+        if (rc) return rc;
+        end_control(ctx);
+        return RSX_OK;
+    }
+    // count phase of the one pass (mod.rs:90-109)
+    rc = hist_dispatch(ctx, d_data, geom, L, 0, J_of(ctx, 0), nullptr, false, st);
     if (rc) return rc;
     if (counting_path) {
         // u8 / i8: the element is its digit, so the 256 counts ARE the sorted array (same bytes as
@@ -345,27 +487,7 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
         ctx->last_path = 3;
         return RSX_OK;
     }
-    // pass loop with ping-pong (mod.rs:84-89); the prefix phase (mod.rs:110-120) is the prologue of each sweep
-    ctx->last_sort_passes = D;
-    ctx->cb_last = ctx->cb;
-    for (uint32_t d = 0; d < D; ++d) {
-        const void* src = (d % 2 == 0) ? d_data : d_tmp;
-        void* dst = (d % 2 == 0) ? d_tmp : d_data;
-        unsigned long long* jnext = (d + 1 < D) ? J_of(ctx, (d + 1) % 3) : nullptr;
-        unsigned long long* jzero = (d + 2 < D) ? J_of(ctx, (d + 2) % 3) : nullptr;
-        const int xf = (d == 0 ? 1 : 0) | (d + 1 == D ? 2 : 0);  // key map on at the first, off at the last pass
-        ctx->pass_index = d;
-        ctx->pass_last = d + 1 == D;
-        ctx->pass_mid = d == 0 ? mid_mode : 0u;  // (2: the first LSD pass also reports whether the top digit's buckets would fit)
-        rc = sweep_dispatch(ctx, src, dst, geom, L, d, J_of(ctx, d % 3), jnext, jzero, xf, st);  // mod.rs:121-168
-        ctx->pass_mid = 0;
-        if (rc) return rc;
-    }
-
-    if (D % 2 == 1)  // odd-D copy-back (mod.rs:170-174)
-        RSX_HIP(hipMemcpyAsync(d_data, d_tmp, n * (size_t)L->elem_bytes, hipMemcpyDeviceToDevice, st));
-    end_control(ctx);
-    return RSX_OK;
+    return fail(ctx, RSX_ERR_INTERNAL, "sort_device_locked: unreachable");
 }
 
 }  // namespace
@@ -446,6 +568,7 @@ int rsx_ctx_destroy(rsx_ctx* ctx) try {
             if (e) (void)hipEventDestroy(e);
         if (ctx->part_J) (void)hipFree(ctx->part_J);
         if (ctx->ovf16) (void)hipFree(ctx->ovf16);
+        if (ctx->wide_buf) (void)hipFree(ctx->wide_buf);
         if (ctx->shard_q) (void)hipFree(ctx->shard_q);
         if (ctx->shard_out) (void)hipFree(ctx->shard_out);
         if (ctx->shard_hist) (void)hipFree(ctx->shard_hist);
@@ -535,6 +658,12 @@ int rsx_ctx_set_option(rsx_ctx* ctx, int option, uint64_t value) try {
             if (value > 1) return fail(ctx, RSX_ERR_ARG, "RSX_OPT_SMALL_SORT: 0 or 1");
             flag(OPT_NO_SMALL_SORT, value == 0);
             return RSX_OK;
+        case RSX_OPT_WIDE_SORT:
+            if (value > 3) return fail(ctx, RSX_ERR_ARG, "RSX_OPT_WIDE_SORT: 0 (off), 1 (auto), 2 (always) or 3 (auto from 2^22 elements on)");
+            ctx->wide_mode = (uint32_t)value;
+            ctx->wide_skip = 0;  // setting the option forgets an earlier refusal
+            if (ctx->host_err) reinterpret_cast<volatile uint32_t*>(ctx->host_err)[9] = 0;
+            return RSX_OK;
         case RSX_OPT_MID_SORT:
             if (value > 3) return fail(ctx, RSX_ERR_ARG, "RSX_OPT_MID_SORT: 0 (off), 1 (forecast), 2 (always split) or 3 (always LSD passes)");
             flag(OPT_NO_MID_SORT, value == 0);
@@ -565,14 +694,21 @@ int rsx_ctx_get_info(rsx_ctx* ctx, int what, uint64_t* out) try {
             if (!ctx->aux || ctx->last_sort_passes == 0) return RSX_OK;
             if (ctx->busy) RSX_HIP(hipEventSynchronize(ctx->last_event));
             uint64_t stat = 0, placed = 0;
-            for (uint32_t p = 0; p < ctx->last_sort_passes && p < (uint32_t)MAX_PASSES; ++p) {
+            uint32_t path = ctx->last_path, passes = ctx->last_sort_passes;
+            if (path == 5 && ctx->wide_buf) {  // both sequences were enqueued: the device's verdict says which one ran
+                uint32_t verdict = 0;
+                RSX_HIP(hipMemcpy(&verdict, reinterpret_cast<uint64_t*>(ctx->wide_buf) + 65536 + 256 + 65537, sizeof verdict, hipMemcpyDeviceToHost));
+                if (verdict == 1u) passes = 2;
+                else path = 0;
+            }
+            for (uint32_t p = 0; p < passes && p < (uint32_t)MAX_PASSES; ++p) {
                 uint32_t mode = 0;  // the roll call's verdict word: 1 static, 3 static + placement verified, 2 / 0 tickets
                 RSX_HIP(hipMemcpy(&mode, reinterpret_cast<uint32_t*>(cb_of(ctx, ctx->cb_last) + CB_TICKETS) + (size_t)p * TICKET_WORDS + ROLL_MODE,
                                   sizeof mode, hipMemcpyDeviceToHost));
                 stat += (mode == 1u || mode == 3u) ? 1u : 0u;
                 placed += mode == 3u ? 1u : 0u;
             }
-            *out = (uint64_t)ctx->last_sort_passes | (stat << 8) | (placed << 16) | ((uint64_t)ctx->last_path << 24);
+            *out = (uint64_t)passes | (stat << 8) | (placed << 16) | ((uint64_t)path << 24);
             return RSX_OK;
         }
         default: return fail(ctx, RSX_ERR_ARG, "unknown info id");

@@ -260,6 +260,17 @@ struct CleanList {
     uint4* p[3];
     uint64_t n16[3];
 };
+// Large arrays of wide keys are enqueued as TWO alternative kernel sequences (the 16-bit bucket hybrid and the LSD passes);
+// which one runs is decided on the device by rsx_scan16_kernel: a gated kernel returns at once unless *word == value
+// (word == null: no gate).  A launch that returns at once costs ~5 us, nothing beside these sorts' milliseconds.
+struct Gate {
+    const uint32_t* word;
+    uint32_t value;
+};
+__device__ __forceinline__ bool gate_open(const Gate& g) {
+    if (g.word == nullptr) return true;
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(g.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == g.value;
+}
 
 // --------------------------------------------------------------- histogram --
 #ifndef RSX_HIST_NT
@@ -273,28 +284,10 @@ struct CleanList {
 #ifndef RSX_HIST_UNROLL
 #define RSX_HIST_UNROLL 1  // more loads in flight per thread measured slower (0.217 -> 0.228 ms per 2^28 u32 at 4)
 #endif
-// Count phase for ONE digit with chunk == region: J[r][v] for the pass's input.
-// grid = num_regions * blocks_per_region; a block stays inside one region.
-// (Only the first pass of a sort needs this kernel: each sweep pass counts the
-// next pass's digit per destination region while it scatters.)
-// TWO: a second digit (spec2) is counted into a second matrix (J2) on the same read -- the middle-size path
-// counts the least significant digit (its first LSD pass) and the most significant one (its bucket split).
-template <int ES, bool FLT, bool TWO = false>
-__global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restrict__ src, RegionGeom g,
-                                                       DigitSpec spec, uint32_t blocks_per_region,
-                                                       unsigned long long* __restrict__ J,
-                                                       unsigned long long* __restrict__ jclear, uint32_t j32,
-                                                       uint4* __restrict__ zero16, uint64_t zero16_n,
-                                                       CleanList clean,
-                                                       DigitSpec spec2 = DigitSpec{}, unsigned long long* __restrict__ J2 = nullptr) {
-    // One-byte elements make 16 LDS atomics per 16-byte load, and random bins collide on the 32 banks (72 % of this
-    // kernel's LDS cycles were bank conflicts: profiles/r03_u8-256m_pmc.txt): their histogram is kept in 32 copies,
-    // copy l in bank l -- lane l of either half-wave adds to lh[bin * 32 + l % 32], so an instruction never has two
-    // lanes on one bank or one address, whatever the skew, and needs no duplicate check.
-    constexpr bool BANKED = ES == 1 && !TWO;
-    __shared__ uint32_t lh[BANKED ? 32 * RADIX : TWO ? 2 * RADIX : RADIX];
+// What a sort's first count kernel does on its way (one launch instead of four):
+__device__ __forceinline__ void count_side_jobs(const RegionGeom& g, unsigned long long* __restrict__ jclear, uint4* __restrict__ zero16,
+                                                uint64_t zero16_n, const CleanList& clean) {
     const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < (BANKED ? 32u * RADIX : TWO ? 2u * RADIX : (uint32_t)RADIX); i += blockDim.x) lh[i] = 0;
     // the count matrix the first sweep accumulates into (the second pass's) is cleared here
     if (jclear != nullptr)
         for (uint32_t i = blockIdx.x * blockDim.x + tid; i < (uint32_t)J_REPL * g.num_regions * RADIX; i += gridDim.x * blockDim.x)
@@ -307,6 +300,32 @@ __global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restric
     for (int z = 0; z < 3; ++z)
         for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + tid; i < clean.n16[z]; i += (uint64_t)gridDim.x * blockDim.x)
             clean.p[z][i] = make_uint4(0, 0, 0, 0);
+}
+
+// Count phase for ONE digit with chunk == region: J[r][v] for the pass's input.
+// grid = num_regions * blocks_per_region; a block stays inside one region.
+// (Only the first pass of a sort needs this kernel: each sweep pass counts the
+// next pass's digit per destination region while it scatters.)
+// TWO: a second digit (spec2) is counted into a second matrix (J2) on the same read -- the middle-size path
+// counts the least significant digit (its first LSD pass) and the most significant one (its bucket split).
+template <int ES, bool FLT, bool TWO = false>
+__global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restrict__ src, RegionGeom g,
+                                                       DigitSpec spec, uint32_t blocks_per_region,
+                                                       unsigned long long* __restrict__ J,
+                                                       unsigned long long* __restrict__ jclear, uint32_t j32,
+                                                       uint4* __restrict__ zero16, uint64_t zero16_n,
+                                                       CleanList clean, Gate gate,
+                                                       DigitSpec spec2 = DigitSpec{}, unsigned long long* __restrict__ J2 = nullptr) {
+    if (!gate_open(gate)) return;
+    // One-byte elements make 16 LDS atomics per 16-byte load, and random bins collide on the 32 banks (72 % of this
+    // kernel's LDS cycles were bank conflicts: profiles/r03_u8-256m_pmc.txt): their histogram is kept in 32 copies,
+    // copy l in bank l -- lane l of either half-wave adds to lh[bin * 32 + l % 32], so an instruction never has two
+    // lanes on one bank or one address, whatever the skew, and needs no duplicate check.
+    constexpr bool BANKED = ES == 1 && !TWO;
+    __shared__ uint32_t lh[BANKED ? 32 * RADIX : TWO ? 2 * RADIX : RADIX];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < (BANKED ? 32u * RADIX : TWO ? 2u * RADIX : (uint32_t)RADIX); i += blockDim.x) lh[i] = 0;
+    count_side_jobs(g, jclear, zero16, zero16_n, clean);
     __syncthreads();
     const uint32_t r = blockIdx.x / blocks_per_region;
     const uint32_t sub = blockIdx.x % blocks_per_region;
@@ -446,6 +465,7 @@ struct SweepArgs {
     uint32_t mid_cap;             // largest bucket rsx_bucket_sort_kernel sorts in LDS
     uint32_t mid_mode;
     uint32_t* mid_hint;
+    Gate gate;                    // wide keys: this sweep belongs to one of two alternative sequences
     uint32_t dbg;                 // RSX_TUNING builds: timing-only ablation switches (0 in production)
     unsigned long long* dbg_cnt;  // [8] diagnostic counters (RSX_TUNING, dbg & 0x100)
 };
@@ -649,6 +669,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
     uint32_t* s_misc = s_jn + (NEXT ? a.g.num_regions * RADIX : 0);                    // [32]
     static_assert(NWAVE * RADIX * sizeof(Cnt) >= RADIX * sizeof(uint64_t), "s_base must fit in s_whist");
 
+    if (!gate_open(a.gate)) return;
     const E* __restrict__ src = static_cast<const E*>(a.src);
     S* status = static_cast<S*>(a.status);
     const uint32_t NR = a.g.num_regions;

@@ -83,6 +83,10 @@ struct rsx_ctx {
     void* pinned[4] = {nullptr, nullptr, nullptr, nullptr};  // ring of pinned bounce chunks
     hipEvent_t copy_event[4] = {nullptr, nullptr, nullptr, nullptr};
     // multi-GPU driver (rsx_sort_sharded): per-slice stream and splitter-search scratch, made once
+    rsx::Gate gate = {nullptr, 0};  // set around the launches of a gated kernel sequence (wide keys)
+    uint32_t wide_skip = 0;     // sorts to go without trying the wide-key hybrid (the last try was refused on the device)
+    char* wide_buf = nullptr;   // wide-key hybrid: bin totals [65536] u64, bin-block sums [256] u64, bucket starts [65537] u64, verdict u32
+    uint32_t wide_mode = 1;     // RSX_OPT_WIDE_SORT: 0 off, 1 auto, 2 always
     uint32_t* ovf16 = nullptr;  // u16 / i16 counting path: 65536 overflow counters, all zero between sorts
     unsigned long long* part_J = nullptr;  // rsx_partition_count_device: one count matrix per sub-range (PART_MAX_SUB x J_BYTES)
     hipStream_t shard_stream = nullptr;
@@ -307,6 +311,16 @@ int launch_hist2(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_l
 // first half of a middle-size sort: stable split of `src` into `dst` by the most significant digit (three launches)
 template <int ES>
 int launch_mid_split(rsx_ctx* ctx, const void* src, void* dst, size_t n, const rsx_layout* L, hipStream_t st);
+// wide keys, large arrays: the top 16 bits of the mapped key counted per workgroup (P[parts][32768]); the 65536
+// buckets (starts[65537]) sorted by the lower digits in LDS, in place
+template <int ES>
+int launch_count16top(rsx_ctx* ctx, const void* src, size_t n, const rsx_layout* L, uint32_t* P, uint32_t parts, uint32_t region_shift,
+                      uint32_t k, hipStream_t st);
+template <int ES>
+int launch_marginal16(rsx_ctx* ctx, const uint32_t* P, uint32_t parts, uint32_t k, const RegionGeom& g, unsigned long long* J,
+                      unsigned long long* jclear, hipStream_t st);
+template <int ES>
+int launch_bucket16(rsx_ctx* ctx, void* data, void* scratch, size_t n, const rsx_layout* L, const uint64_t* starts, hipStream_t st);
 // second half of a middle-size sort: the 256 top-digit buckets of `src` sorted by the lower digits into `dst`
 template <int ES>
 int launch_bucket_sort(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L, hipStream_t st);

@@ -25,7 +25,7 @@ int launch_hist_t(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_
     LaunchTimer lt(ctx, RSX_PROF_HIST, st);
     hipLaunchKernelGGL((rsx_hist_kernel<ES, FLT>), dim3((uint32_t)(bpr * g.num_regions)), dim3(512), 0, st,
                        static_cast<const Elem<ES>*>(src), g, make_spec(L, digit), (uint32_t)bpr, J, jclear, status32(g) ? 1u : 0u,
-                       static_cast<uint4*>(ctx->status), zero16_n, ctx->clean);
+                       static_cast<uint4*>(ctx->status), zero16_n, ctx->clean, ctx->gate);
     RSX_HIP(hipGetLastError());
     ctx->clean = CleanList{{nullptr, nullptr, nullptr}, {0, 0, 0}};  // done once per sort
     return RSX_OK;
@@ -52,11 +52,11 @@ int launch_hist2(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_l
     if (L->key_kind != RSX_KEY_UNSIGNED)
         hipLaunchKernelGGL((rsx_hist_kernel<ES, true, true>), dim3((uint32_t)(bpr * g.num_regions)), dim3(512), 0, st,
                            static_cast<const Elem<ES>*>(src), g, make_spec(L, digit), (uint32_t)bpr, J, jclear, status32(g) ? 1u : 0u,
-                           static_cast<uint4*>(ctx->status), zero16_n, ctx->clean, make_spec(L, digit2), J2);
+                           static_cast<uint4*>(ctx->status), zero16_n, ctx->clean, ctx->gate, make_spec(L, digit2), J2);
     else
         hipLaunchKernelGGL((rsx_hist_kernel<ES, false, true>), dim3((uint32_t)(bpr * g.num_regions)), dim3(512), 0, st,
                            static_cast<const Elem<ES>*>(src), g, make_spec(L, digit), (uint32_t)bpr, J, jclear, status32(g) ? 1u : 0u,
-                           static_cast<uint4*>(ctx->status), zero16_n, ctx->clean, make_spec(L, digit2), J2);
+                           static_cast<uint4*>(ctx->status), zero16_n, ctx->clean, ctx->gate, make_spec(L, digit2), J2);
     RSX_HIP(hipGetLastError());
     ctx->clean = CleanList{{nullptr, nullptr, nullptr}, {0, 0, 0}};
     return RSX_OK;
@@ -123,6 +123,7 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
     a.mid_J = nullptr;
     a.mid_spec = a.spec;
     a.mid_cap = 0;
+    a.gate = ctx->gate;
     a.mid_mode = ctx->pass_mid;
     a.mid_hint = ctx->host_err_dev + 8;  // second word group of the host-visible block
     if constexpr (MID) {
@@ -342,6 +343,89 @@ int launch_bucket_sort(rsx_ctx* ctx, const void* src, void* dst, const RegionGeo
             }
             hipLaunchKernelGGL(kern, dim3(RADIX), dim3(1024), lds, st, a);
         }
+        RSX_HIP(hipGetLastError());
+        return RSX_OK;
+    }
+}
+
+// ---- wide keys, large arrays: count of the top 16 bits; the buckets sorted in LDS -------------------
+template <int ES>
+int launch_count16top(rsx_ctx* ctx, const void* src, size_t n, const rsx_layout* L, uint32_t* P, uint32_t parts, uint32_t region_shift,
+                      uint32_t k, hipStream_t st) {
+    if constexpr (ES < 4) {
+        return fail(ctx, RSX_ERR_INTERNAL, "launch_count16top: narrow elements");
+    } else {
+        const DigitSpec lo = make_spec(L, L->key_bytes - 2), hi = make_spec(L, L->key_bytes - 1);
+        LaunchTimer lt(ctx, RSX_PROF_HIST, st);
+        if (L->key_kind != RSX_KEY_UNSIGNED) {
+            auto kern = rsx_count16top_kernel<ES, true>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            hipLaunchKernelGGL(kern, dim3(parts), dim3(1024), 131072, st, static_cast<const Elem<ES>*>(src), (uint64_t)n, lo, hi, P, ctx->ovf16,
+                               region_shift, k);
+        } else {
+            auto kern = rsx_count16top_kernel<ES, false>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            hipLaunchKernelGGL(kern, dim3(parts), dim3(1024), 131072, st, static_cast<const Elem<ES>*>(src), (uint64_t)n, lo, hi, P, ctx->ovf16,
+                               region_shift, k);
+        }
+        RSX_HIP(hipGetLastError());
+        return RSX_OK;
+    }
+}
+
+// the first sweep's count matrix from the counters of launch_count16top (k chunks per region), + the side jobs of launch_hist
+template <int ES>
+int launch_marginal16(rsx_ctx* ctx, const uint32_t* P, uint32_t parts, uint32_t k, const RegionGeom& g, unsigned long long* J,
+                      unsigned long long* jclear, hipStream_t st) {
+    const uint64_t zero16_n = status_rows(g, ES) * RADIX * (status32(g) ? 4u : 8u) / 16u;
+    uint32_t grid = (uint32_t)ctx->num_cu * 8u;
+    if (grid < parts) grid = parts;
+    LaunchTimer lt(ctx, RSX_PROF_HIST, st);
+    hipLaunchKernelGGL(rsx_marginal16_kernel<ES>, dim3(grid), dim3(256), 0, st, P, parts, k, g, J, jclear, status32(g) ? 1u : 0u,
+                       static_cast<uint4*>(ctx->status), zero16_n, ctx->clean, ctx->gate);
+    RSX_HIP(hipGetLastError());
+    ctx->clean = CleanList{{nullptr, nullptr, nullptr}, {0, 0, 0}};
+    return RSX_OK;
+}
+
+template <int ES>
+int launch_bucket16(rsx_ctx* ctx, void* data, void* scratch, size_t n, const rsx_layout* L, const uint64_t* starts, hipStream_t st) {
+    if constexpr (ES < 4) {
+        return fail(ctx, RSX_ERR_INTERNAL, "launch_bucket16: narrow elements");
+    } else {
+        constexpr int KPT = bucket_kpt_for(ES);
+        if (L->key_bytes < 4) return fail(ctx, RSX_ERR_INTERNAL, "launch_bucket16: key width out of range");
+        SmallArgs a;
+        std::memset(&a, 0, sizeof a);
+        a.src = data;
+        a.data = data;
+        a.passes = L->key_bytes - 2;
+        a.rank_atomic = (ctx->rank_atomic && !(ctx->options & OPT_BALLOT_RANKS)) ? 1u : 0u;
+        a.map_load = 0;  // the first sweep mapped the keys
+        a.map_store = L->key_kind == RSX_KEY_UNSIGNED ? 0u : 1u;
+        for (uint32_t d = 0; d + 2 < L->key_bytes; ++d) {
+            a.spec[d] = make_spec(L, d);
+            a.spec[d].flip = 0;
+        }
+        a.xf = make_xform(L);
+        a.cap = bucket_cap(ES);
+        LaunchTimer lt(ctx, RSX_PROF_OTHER, st);
+        // workgroup size by the AVERAGE bucket (a few buckets above the capacity go through memory): 256, 512 or 1024
+        // threads x KPT elements, as many workgroups per CU as their LDS allows (3-4, 2, 1)
+        const uint64_t avg = (uint64_t)n / 65536u;
+        auto go = [&](auto wgc) {
+            constexpr int WGS = decltype(wgc)::value;
+            const size_t lds = (size_t)WGS * KPT * ES + (WGS / 64) * RADIX * sizeof(uint32_t) + 64 + 3 * RADIX * sizeof(uint32_t);
+            auto kern = rsx_bucket16_kernel<ES, KPT, WGS>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            int per_cu = (int)((size_t)163840 / lds);
+            if (per_cu < 1) per_cu = 1;
+            if (per_cu > 2048 / WGS) per_cu = 2048 / WGS;
+            hipLaunchKernelGGL(kern, dim3((uint32_t)(ctx->num_cu * per_cu)), dim3(WGS), lds, st, a, starts, scratch, ctx->gate);
+        };
+        if (avg <= (uint64_t)256 * KPT) go(std::integral_constant<int, 256>{});
+        else if (avg <= (uint64_t)512 * KPT) go(std::integral_constant<int, 512>{});
+        else go(std::integral_constant<int, 1024>{});
         RSX_HIP(hipGetLastError());
         return RSX_OK;
     }

@@ -166,4 +166,99 @@ __global__ __launch_bounds__(512) void rsx_tilescatter_kernel(const MidArgs a) {
     }
 }
 
+// ---- wide keys, large arrays: two passes through memory for the top 16 bits, the rest in LDS ---------------------
+// Eight-byte keys take eight sweeps of 2 n s bytes each.  A pass INSIDE LDS (rsx_small_kernel.hpp local_sort) costs a
+// workgroup about half of what a sweep costs it per key -- no HBM, no look-back --, so when the top 16 bits of the
+// mapped key spread the array over their 65536 buckets evenly enough for every bucket to fit a workgroup's LDS, the
+// sort is: count those 16 bits (this kernel + rsx_total16_kernel + rsx_scan16_kernel), two ordinary LSD sweeps on
+// digits D-2 and D-1 (after which every bucket is contiguous and in input order), and rsx_bucket16_kernel: every
+// bucket sorted by its remaining D-2 digits in LDS.  Same bytes as D LSD passes (the stable sort by the whole key).
+//
+// rsx_count16top_kernel: as rsx_count16_kernel (65536 16-bit LDS counters per workgroup, returned atomics, overflow
+// parked in a global table), over elements of ES bytes whose bin is (digit D-1, digit D-2) of the mapped key.
+// Workgroup b counts chunk b % k of region b / k (k chunks per region; k == 0: the array cut into gridDim.x flat
+// shares): a workgroup then stays inside ONE region of the sweeps' geometry, and the count matrix of the first sweep
+// (digit D-2 = the low byte of the bin, per region) is a marginal of these counters -- rsx_marginal16_kernel reads
+// them back (32 MiB) instead of a count kernel reading the array again (1.37 ms of 21 on 2^30 u64).
+template <int ES, bool FLT>
+__global__ __launch_bounds__(1024) void rsx_count16top_kernel(const Elem<ES>* __restrict__ src, uint64_t n, DigitSpec lo, DigitSpec hi,
+                                                              uint32_t* __restrict__ P, uint32_t* __restrict__ ovf, uint32_t region_shift,
+                                                              uint32_t k) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem16);  // [32768]
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < 32768u / 4u; i += 1024u) reinterpret_cast<uint4*>(cnt)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    uint64_t p0, p1;
+    if (k == 0) {
+        const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
+        p0 = (uint64_t)blockIdx.x * per;
+        p1 = p0 + per;
+    } else {
+        const uint64_t rl = 1ull << region_shift, per = (rl + k - 1) / k;
+        const uint64_t r0 = (uint64_t)(blockIdx.x / k) << region_shift;
+        p0 = r0 + (uint64_t)(blockIdx.x % k) * per;
+        p1 = p0 + per;
+        if (p1 > r0 + rl) p1 = r0 + rl;
+    }
+    if (p1 > n) p1 = n;
+    auto count = [&](const Elem<ES>& e) {
+        const uint32_t bin = (elem_digit<ES, FLT>(e, hi) << 8) | elem_digit<ES, FLT>(e, lo);
+        const uint32_t sh = (bin & 1u) * 16u;
+        const uint32_t old = atomicAdd(&cnt[bin >> 1], 1u << sh);
+        if (((old >> sh) & 0xFFFFu) == 0x7FFFu) {  // my add made it 0x8000: park that half in the overflow table
+            atomicSub(&cnt[bin >> 1], 0x8000u << sh);
+            atomicAdd(&ovf[bin], 0x8000u);
+        }
+    };
+    constexpr int UNR = ES <= 8 ? 8 : ES <= 16 ? 4 : 2;  // loads in flight per thread (one workgroup per CU: 16 waves)
+    uint64_t i = p0 + tid;
+    for (; i + (uint64_t)(UNR - 1) * 1024u < p1; i += (uint64_t)UNR * 1024u) {
+        Elem<ES> e[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) e[u] = src[i + (uint64_t)u * 1024u];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) count(e[u]);
+    }
+    for (; i < p1; i += 1024u) count(src[i]);
+    __syncthreads();
+    uint4* out = reinterpret_cast<uint4*>(P + (size_t)blockIdx.x * 32768u);
+    for (uint32_t i4 = tid; i4 < 32768u / 4u; i4 += 1024u) out[i4] = reinterpret_cast<const uint4*>(cnt)[i4];
+}
+
+// The first sweep's count matrix from the 16-bit counters: J[rep][r][v] += sum over the top byte h of P[b][h * 256 + v]
+// for workgroup b of rsx_count16top_kernel (region r = b / k).  Valid when no counter overflowed, which is the case
+// whenever the hybrid is taken on the device's verdict: a bucket that fits a workgroup's LDS holds fewer than 0x8000
+// elements.  Also does the jobs of a sort's first count kernel (count_side_jobs).  grid >= parts (the workgroups
+// beyond only help with those jobs), block = 256.  (A template only so that every element-size unit owns its copy.)
+template <int ES>
+__global__ __launch_bounds__(256) void rsx_marginal16_kernel(const uint32_t* __restrict__ P, uint32_t parts, uint32_t k, RegionGeom g,
+                                                             unsigned long long* __restrict__ J, unsigned long long* __restrict__ jclear,
+                                                             uint32_t j32, uint4* __restrict__ zero16, uint64_t zero16_n, CleanList clean,
+                                                             Gate gate) {
+    if (!gate_open(gate)) return;
+    __shared__ uint32_t part[2][RADIX];
+    count_side_jobs(g, jclear, zero16, zero16_n, clean);
+    if (blockIdx.x >= parts) return;
+    const uint32_t tid = threadIdx.x, c = tid & 127u, half = tid >> 7;
+    const uint32_t* row = P + (size_t)blockIdx.x * 32768u;
+    uint32_t lo = 0, hi = 0;
+#pragma unroll 8
+    for (uint32_t h = half; h < 256u; h += 2u) {
+        const uint32_t w = row[h * 128u + c];
+        lo += w & 0xFFFFu;
+        hi += w >> 16;
+    }
+    part[half][2u * c] = lo;
+    part[half][2u * c + 1u] = hi;
+    __syncthreads();
+    const uint32_t sum = part[0][tid] + part[1][tid];
+    const uint32_t r = blockIdx.x / k;
+    const uint32_t bin = ((blockIdx.x % J_REPL) * g.num_regions + r) * RADIX + tid;
+    if (sum) {
+        if (j32) atomicAdd(reinterpret_cast<uint32_t*>(J) + bin, sum);
+        else atomicAdd(&J[bin], (unsigned long long)sum);
+    }
+}
+
 }  // namespace rsx

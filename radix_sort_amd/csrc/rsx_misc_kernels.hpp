@@ -214,6 +214,44 @@ __global__ __launch_bounds__(256) void rsx_total16_kernel(const uint32_t* __rest
     if (tid == 0) BT[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
+// Exclusive scan of the 65536 bin totals (one workgroup: 64 bins per thread) -> starts[65537]; *verdict = 1 if no bin
+// exceeds `cap`, else 2 (wide keys: whether every 16-bit bucket fits a workgroup's LDS).
+__global__ __launch_bounds__(1024) void rsx_scan16_kernel(const uint64_t* __restrict__ tot, uint64_t* __restrict__ starts, uint64_t cap,
+                                                          uint32_t* __restrict__ verdict, uint32_t* __restrict__ host_verdict) {
+    __shared__ uint64_t ws[16];
+    __shared__ uint32_t wbig[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint64_t mine = 0, big = 0;
+    for (int k = 0; k < 64; ++k) {
+        const uint64_t c = tot[(size_t)tid * 64 + k];
+        mine += c;
+        big = c > big ? c : big;
+    }
+    uint64_t x = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t y = __shfl_up(x, o);
+        if (lane >= (uint32_t)o) x += y;
+    }
+    const uint64_t over = __ballot(big > cap);
+    if (lane == 63) ws[wave] = x;
+    if (lane == 0) wbig[wave] = over != 0 ? 1u : 0u;
+    __syncthreads();
+    uint64_t run = x - mine;
+    for (uint32_t w = 0; w < wave; ++w) run += ws[w];
+    for (int k = 0; k < 64; ++k) {
+        starts[(size_t)tid * 64 + k] = run;
+        run += tot[(size_t)tid * 64 + k];
+    }
+    if (tid == 1023) starts[65536] = run;
+    if (tid == 0) {
+        uint32_t any = 0;
+        for (int w = 0; w < 16; ++w) any |= wbig[w];
+        *verdict = any ? 2u : 1u;
+        __hip_atomic_store(host_verdict, any ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // the host's forecast for later sorts
+    }
+}
+
 // Writes the runs.  The output is cut into 1 KiB steps (64 lanes x 8 elements); a wave takes every 4th step of its
 // workgroup's contiguous share.  Two-level search: the 256 bin-block starts (scan of BT, per workgroup, in LDS) and
 // the 256 bin starts inside the block at hand (scan of its tot[], per wave, in LDS, reloaded when the wave moves on).

@@ -297,4 +297,27 @@ __global__ __launch_bounds__(WG) void rsx_bucket_sort_kernel(const SmallArgs a) 
                               (uint32_t)count, smem);
 }
 
+// Wide keys, large arrays (rsx_mid_kernels.hpp, rsx_count16top_kernel): the array is partitioned by the top 16 bits of
+// the mapped key; starts[b] .. starts[b + 1] is bucket b.  Persistent workgroups take the buckets round-robin and sort
+// each by the remaining digits in LDS, in place; one that does not fit goes through memory (`scratch`, same offsets).
+// WG: 1024 threads (one workgroup per CU), or 256 where the average bucket fits a quarter of that: three workgroups per
+// CU then work on three buckets at once (2^28 u64 keys: the buckets hold 4096).
+template <int ES, int KPT, int WG>
+__global__ __launch_bounds__(WG) void rsx_bucket16_kernel(const SmallArgs a, const uint64_t* __restrict__ starts, void* scratch, Gate gate) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (!gate_open(gate)) return;
+    for (uint32_t b = blockIdx.x; b < 65536u; b += gridDim.x) {
+        const uint64_t start = starts[b];
+        const uint64_t count = starts[b + 1] - start;  // (the same for every thread: uniform control flow below)
+        if (count == 0) continue;
+        Elem<ES>* bucket = static_cast<Elem<ES>*>(a.data) + start;
+        if (count > (uint64_t)WG * KPT) {  // an even number of passes: ends where it began
+            big_bucket_sort<ES, KPT, WG>(a, bucket, static_cast<Elem<ES>*>(scratch) + start, (uint32_t)count, smem);
+        } else {
+            local_sort<ES, KPT, WG>(a, bucket, bucket, (uint32_t)count, smem);
+        }
+        __syncthreads();  // smem belongs to the next bucket
+    }
+}
+
 }  // namespace rsx

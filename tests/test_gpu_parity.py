@@ -122,6 +122,81 @@ def test_middle_size_forecast_and_oversized_buckets(rs, torch, orc, t):
     c.close()
 
 
+WIDE_TYPES = [t for t in util.TYPES if util.TYPES[t][0] >= 8 and util.TYPES[t][2] >= 8]
+
+
+@pytest.mark.parametrize("t", WIDE_TYPES)
+def test_wide_key_hybrid_forced(rs, torch, orc, t):
+    """RSX_OPT_WIDE_SORT = 2: the top 16 bits of the key counted, two sweeps for those digits, every 16-bit bucket sorted
+    by its remaining digits in LDS -- forced on every distribution (skewed ones put everything into a few buckets, which
+    then go through memory, workgroup by workgroup), for every element type with a key of at least 8 bytes."""
+    d = _digits(rs, t)
+    lay = orc.Layout(*util.TYPES[t])
+    c = rs.Context(torch.cuda.current_device())
+    c.set_option(rs.OPT_WIDE_SORT, 2)
+    rng = np.random.default_rng(31 + d.elem_bytes)
+    for i, dist in enumerate(util.DISTS):
+        n = int(rng.integers(70000, 400000))
+        raw = util.make_input(t, n, dist, seed=300 + i)
+        x = torch.from_numpy(raw.copy()).cuda()
+        rs.radix_sort(x, digits=d, ctx=c)
+        c.check()
+        assert np.array_equal(x.cpu().numpy(), orc.sort_parallel(raw, lay, 8)), (t, n, dist)
+    c.close()
+
+
+@pytest.mark.parametrize("t", WIDE_TYPES)
+def test_wide_key_hybrid_counts_from_the_16_bit_counters(rs, torch, orc, t):
+    """RSX_OPT_WIDE_SORT = 3 (the default mode without its 2 GiB floor): ragged sizes above the middle sizes.  The count's
+    workgroups are laid out k per region, the first sweep's count matrix is taken from their counters (no second read of
+    the array); a uniform input takes the hybrid (path 5 reported), a skewed one is refused on the device (path 0)."""
+    d = _digits(rs, t)
+    lay = orc.Layout(*util.TYPES[t])
+    mm = _mid_max(d.elem_bytes)
+    c = rs.Context(torch.cuda.current_device())
+    c.set_option(rs.OPT_WIDE_SORT, 3)
+    rng = np.random.default_rng(97 + d.elem_bytes)
+    for i, (dist, path) in enumerate((("uniform", 5), ("uniform", 5), ("zipf", 0), ("uniform", 5))):
+        n = mm + int(rng.integers(1, mm // 2))
+        raw = util.make_input(t, n, dist, seed=900 + i)
+        x = torch.from_numpy(raw.copy()).cuda()
+        rs.radix_sort(x, digits=d, ctx=c)
+        c.check()
+        info = c.get_info(rs.INFO_LAST_PASSES)
+        assert (info >> 24) & 15 == path and info & 255 == (2 if path == 5 else d.key_bytes), (t, n, dist, hex(info))
+        assert np.array_equal(x.cpu().numpy(), orc.sort_parallel(raw, lay, 8)), (t, n, dist)
+        if path == 0:
+            c.set_option(rs.OPT_WIDE_SORT, 3)  # (a refusal is followed by 15 sorts without a try: start over)
+    c.close()
+
+
+def test_wide_key_hybrid_decides_on_the_device(rs, torch, ctx, orc):
+    """Default mode at a size where the hybrid is tried (2 GiB of u64): a uniform input takes it, a Zipf input is
+    refused by the count (the LSD passes run, gated on the same verdict word), and after a refusal the context goes
+    without trying for a while; checked on the device (sorted, multiset unchanged) and against the LSD-only result."""
+    d = rs.PRIMITIVES["u64"]
+    n = 1 << 28
+    c = rs.Context(torch.cuda.current_device())
+    ref = rs.Context(torch.cuda.current_device())
+    ref.set_option(rs.OPT_WIDE_SORT, 0)
+    x = torch.empty(n * 8, dtype=torch.uint8, device="cuda")
+    y = torch.empty_like(x)
+    tmp = torch.empty_like(x)
+    out = torch.zeros(3, dtype=torch.int64, device="cuda")
+    for i, gen in enumerate((rs.GEN_UNIFORM, rs.GEN_ZIPF, rs.GEN_ZIPF, rs.GEN_UNIFORM, rs.GEN_UNIFORM)):
+        c.generate_device(x.data_ptr(), n, d, gen, 50 + i, 1.0)
+        y.copy_(x)
+        c.sort_device(x.data_ptr(), tmp.data_ptr(), n, d)
+        c.check()
+        ref.sort_device(y.data_ptr(), tmp.data_ptr(), n, d)
+        ref.check()
+        assert torch.equal(x, y), (i, gen)
+        c.verify_device(x.data_ptr(), n, d, out.data_ptr())
+        assert out[0].item() == 0
+    c.close()
+    ref.close()
+
+
 @pytest.mark.parametrize("t,extra", [("u32", 1), ("u32", 200), ("u64", 50), ("(u32,u32)", 3), ("f32", 1000)])
 def test_small_bucket_workgroups_meet_an_oversized_bucket(rs, torch, orc, t, extra):
     """After a uniform input the forecast picks 256-thread bucket workgroups (every bucket fitted a quarter of the large
@@ -459,7 +534,9 @@ ALT_PATHS = [("OPT_TILE_SCHEDULE", 1, "ticketed tiles instead of the static roll
              ("OPT_SMALL_SORT", 0, "arrays of at most one tile through the general path"),
              ("OPT_MID_SORT", 0, "middle sizes by LSD passes only (no bucket split)"),
              ("OPT_MID_SORT", 2, "middle sizes always split by the top digit (skewed inputs: oversized buckets through memory)"),
-             ("OPT_MID_SORT", 3, "middle sizes always by LSD passes, top digit counted for the forecast")]
+             ("OPT_MID_SORT", 3, "middle sizes always by LSD passes, top digit counted for the forecast"),
+             ("OPT_WIDE_SORT", 2, "wide keys always by the 16-bit bucket hybrid"),
+             ("OPT_WIDE_SORT", 0, "wide keys never by the 16-bit bucket hybrid")]
 
 
 @pytest.mark.parametrize("opt,value,what", ALT_PATHS)

@@ -1,0 +1,32 @@
+"""Wide-key hybrid (RSX_OPT_WIDE_SORT) against the LSD passes: python tools/wide_probe.py [type ...]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, radix_sort_amd as rs
+import bench
+types = sys.argv[1:] or ["u64"]
+MODES = [int(v) for v in os.environ.get("MODES", "0,1").split(",")]
+LGS = [int(v) for v in os.environ.get("LGS", "24,26,28,29,30").split(",")]
+gen = {"uniform": rs.GEN_UNIFORM, "zipf": rs.GEN_ZIPF}[os.environ.get("GEN", "uniform")]
+for t in types:
+    d = bench.digits_for(rs, t)
+    for lg in LGS:
+        n = 1 << lg
+        if n * d.elem_bytes > (12 << 30): continue
+        x = torch.empty(n * d.elem_bytes, dtype=torch.uint8, device="cuda"); tmp = torch.empty_like(x)
+        out = torch.zeros(3, dtype=torch.int64, device="cuda")
+        res = []
+        for mode in MODES:
+            ctx = rs.Context(0); ctx.set_option(rs.OPT_WIDE_SORT, mode)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            tot = 0.0
+            for it in range(6):
+                ctx.generate_device(x.data_ptr(), n, d, gen, it, 1.0)
+                ctx.verify_device(x.data_ptr(), n, d, out.data_ptr()); torch.cuda.synchronize(); before = out[1].item()
+                e0.record(); ctx.sort_device(x.data_ptr(), tmp.data_ptr(), n, d); e1.record(); torch.cuda.synchronize(); ctx.check()
+                ctx.verify_device(x.data_ptr(), n, d, out.data_ptr()); torch.cuda.synchronize()
+                assert out[0].item() == 0 and out[2].item() == 0 and out[1].item() == before, (t, lg, mode, out.tolist())
+                if it >= 2: tot += e0.elapsed_time(e1)
+            res.append(tot / 4)
+            ctx.close()
+        print(f"{t} 2^{lg}: LSD {res[0]:8.3f} ms  hybrid {res[1]:8.3f} ms  x{res[0]/res[1]:.2f}  ({n/res[1]/1e6:.1f} Gkeys/s)", flush=True)
+        del x, tmp
