@@ -116,11 +116,14 @@ enum {
                                   that is skewed after all is still sorted correctly (an oversized bucket goes through
                                   memory), then the context keeps to LSD passes for its next sorts.  0: LSD passes always,
                                   top digit not even counted.  2: always split.  3: always LSD passes. */,
-    RSX_OPT_WIDE_SORT = 12     /* large arrays of 8-byte (and wider) keys: count the top 16 bits of the key, two sweeps for
+    RSX_OPT_WIDE_SORT = 12,    /* large arrays of 8-byte (and wider) keys: count the top 16 bits of the key, two sweeps for
                                   those two digits, then every 16-bit bucket sorted by its remaining digits in LDS.
                                   0: never; 1 (default): arrays of 2 GiB and more, when the count says every bucket
                                   fits; 2: always (any array of 65536+ such elements, buckets that do not fit go through
                                   memory); 3: as 1 without the size floor (above the middle sizes) */
+    RSX_OPT_BUCKET_SKIP = 13   /* the hybrid's LDS passes: 1 (default) start at the digit that leaves four passes (a 16-bit
+                                  bucket is, as a rule, told apart by its next 32 bits) and put right the neighbours that
+                                  still agree, by the digits skipped; 0: every pass */
 };
 int rsx_ctx_set_option(rsx_ctx *ctx, int option, uint64_t value);
 enum {

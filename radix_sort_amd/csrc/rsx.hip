@@ -664,6 +664,10 @@ int rsx_ctx_set_option(rsx_ctx* ctx, int option, uint64_t value) try {
             ctx->wide_skip = 0;  // setting the option forgets an earlier refusal
             if (ctx->host_err) reinterpret_cast<volatile uint32_t*>(ctx->host_err)[9] = 0;
             return RSX_OK;
+        case RSX_OPT_BUCKET_SKIP:
+            if (value > 1) return fail(ctx, RSX_ERR_ARG, "RSX_OPT_BUCKET_SKIP: 0 or 1");
+            ctx->bucket_no_skip = value == 0 ? 1u : 0u;
+            return RSX_OK;
         case RSX_OPT_MID_SORT:
             if (value > 3) return fail(ctx, RSX_ERR_ARG, "RSX_OPT_MID_SORT: 0 (off), 1 (forecast), 2 (always split) or 3 (always LSD passes)");
             flag(OPT_NO_MID_SORT, value == 0);

@@ -1,6 +1,7 @@
 // rsx_launch_impl.hpp -- definitions of the per-element-size launchers declared in
 // rsx_internal.hpp.  Included only by rsx_es.hip, which instantiates them for ONE element size.
 #pragma once
+#include <cstdlib>
 #include "rsx_internal.hpp"
 #include "rsx_small_kernel.hpp"
 #include "rsx_mid_kernels.hpp"
@@ -409,6 +410,9 @@ int launch_bucket16(rsx_ctx* ctx, void* data, void* scratch, size_t n, const rsx
         }
         a.xf = make_xform(L);
         a.cap = bucket_cap(ES);
+        a.no_skip = ctx->bucket_no_skip;
+        if (a.passes > 4 && !a.no_skip)  // (rsx_bucket16_kernel starts at digit passes - 4: the key bytes from there up)
+            for (uint32_t byte = L->key_offset + a.passes - 4; byte < L->key_offset + L->key_bytes; ++byte) a.cmp_mask[byte >> 2] |= 0xFFu << (8 * (byte & 3));
         LaunchTimer lt(ctx, RSX_PROF_OTHER, st);
         // workgroup size by the AVERAGE bucket (a few buckets above the capacity go through memory): 256, 512 or 1024
         // threads x KPT elements, as many workgroups per CU as their LDS allows (3-4, 2, 1)
@@ -420,7 +424,7 @@ int launch_bucket16(rsx_ctx* ctx, void* data, void* scratch, size_t n, const rsx
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             int per_cu = (int)((size_t)163840 / lds);
             if (per_cu < 1) per_cu = 1;
-            if (per_cu > 2048 / WGS) per_cu = 2048 / WGS;
+            if (per_cu > 4 * RSX_B16_WAVES(WGS) * 64 / WGS) per_cu = 4 * RSX_B16_WAVES(WGS) * 64 / WGS;
             hipLaunchKernelGGL(kern, dim3((uint32_t)(ctx->num_cu * per_cu)), dim3(WGS), lds, st, a, starts, scratch, ctx->gate);
         };
         if (avg <= (uint64_t)256 * KPT) go(std::integral_constant<int, 256>{});

@@ -32,27 +32,25 @@ struct SmallArgs {
     // bucket kernel only
     const uint32_t* top_tot;          // the 256 totals of the top digit (rsx_tilescan_kernel)
     uint32_t cap;                     // elements a 1024-thread workgroup sorts in LDS (a 256-thread one: a quarter)
+    uint32_t no_skip;                 // bucket16 kernel: run every pass (1), or start at the digit that leaves four and mend (0)
+    uint32_t cmp_mask[8];             // ... the bits of the key from that digit up, per element dword
     uint32_t* hint;                   // host-visible report for the host's next forecast: 1 = every bucket of this input fits a
                                       // 256-thread workgroup, 3 = a 1024-thread one, 2 = some bucket fits neither
 };
 
-// Sorts elements [0, n) of `src` by `a.passes` digits into `dst` (same index range), n <= WG * KPT.
+#ifdef RSX_B16_TIMING
+__device__ unsigned long long g_ptm[8];
+#endif
+// The elements of a workgroup's array [0, n) as its threads hold them: wave w holds [w*64*kp, (w+1)*64*kp), round j at
+// +j*64 -- (wave, round, lane) order == index order, so ranks are stable.  kp = ceil(n / WG) rounds are in use.
 template <int ES, int KPT, int WG>
-__device__ __forceinline__ void local_sort(const SmallArgs& a, const Elem<ES>* __restrict__ src, Elem<ES>* __restrict__ dst,
-                                           const uint32_t n, unsigned char* smem) {
-    constexpr int NWAVE = WG / WAVE;
-    using E = Elem<ES>;
-    E* s_elems = reinterpret_cast<E*>(smem);                                              // [WG * KPT]
-    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem + (size_t)WG * KPT * sizeof(E));  // [NWAVE][256]
-    uint32_t* s_misc = s_cnt + NWAVE * RADIX;                                             // [NWAVE]
+__device__ __forceinline__ void local_load(const SmallArgs& a, const Elem<ES>* __restrict__ src, const uint32_t n, Elem<ES> (&e)[KPT]) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t kp = (n + WG - 1) / WG;          // rounds in use, 1..KPT (wave-uniform, the same for all)
-    const uint32_t seg = wave * (WAVE * kp) + lane;  // wave w holds elements [w*64*kp, (w+1)*64*kp), round j at +j*64:
-                                                     // (wave, round, lane) order == index order, so ranks are stable
-    E e[KPT];
+    const uint32_t kp = (n + WG - 1) / WG;
+    const uint32_t seg = wave * (WAVE * kp) + lane;
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
-        e[j] = E{};
+        e[j] = Elem<ES>{};
         if ((uint32_t)j < kp) {
             const uint32_t p = seg + (uint32_t)j * WAVE;
             if (p < n) {
@@ -61,9 +59,35 @@ __device__ __forceinline__ void local_sort(const SmallArgs& a, const Elem<ES>* _
             }
         }
     }
+}
+
+// The a.passes digit passes over the elements in `e` (local_load); the sorted array is left in LDS (s_elems[0, n)).
+template <int ES, int KPT, int WG>
+__device__ __forceinline__ void local_passes(const SmallArgs& a, Elem<ES> (&e)[KPT], const uint32_t n, unsigned char* smem,
+                                             const uint32_t first = 0) {
+    constexpr int NWAVE = WG / WAVE;
+    using E = Elem<ES>;
+    E* s_elems = reinterpret_cast<E*>(smem);                                              // [WG * KPT]
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem + (size_t)WG * KPT * sizeof(E));  // [NWAVE][256]
+    uint32_t* s_misc = s_cnt + NWAVE * RADIX;                                             // [NWAVE]
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t kp = (n + WG - 1) / WG;          // rounds in use, 1..KPT (wave-uniform, the same for all)
+    const uint32_t seg = wave * (WAVE * kp) + lane;
     uint32_t* my = s_cnt + wave * RADIX;
-    for (uint32_t pass = 0; pass < a.passes; ++pass) {
+#ifdef RSX_B16_TIMING
+    uint64_t pt = wall_clock64();
+#define RSX_PTICK(k)                                              \
+    {                                                             \
+        const uint64_t now = wall_clock64();                      \
+        if (blockIdx.x == 7 && tid == 0) g_ptm[k] += now - pt;    \
+        pt = now;                                                 \
+    }
+#else
+#define RSX_PTICK(k)
+#endif
+    for (uint32_t pass = first; pass < a.passes; ++pass) {
         const DigitSpec spec = a.spec[pass];
+        RSX_PTICK(5)
 #pragma unroll
         for (int i = 0; i < RADIX / WAVE; ++i) my[i * WAVE + lane] = 0;
         // the slots past n are padding: digit 255, and being the highest indices they rank behind every real 255
@@ -88,6 +112,7 @@ __device__ __forceinline__ void local_sort(const SmallArgs& a, const Elem<ES>* _
             }
         }
         __syncthreads();
+        RSX_PTICK(0)
         // count -> prefix: start of (digit v, wave w) in the sorted tile, digit-major / wave-minor
         uint32_t tcount = 0, incl = 0;
         if (tid < RADIX) {
@@ -108,22 +133,44 @@ __device__ __forceinline__ void local_sort(const SmallArgs& a, const Elem<ES>* _
             }
         }
         __syncthreads();
+        RSX_PTICK(1)
 #pragma unroll
         for (int j = 0; j < KPT; ++j)
             if ((uint32_t)j < kp) s_elems[my[digit_of(j)] + rk[j]] = e[j];
         __syncthreads();
+        RSX_PTICK(2)
         if (pass + 1 < a.passes) {
 #pragma unroll
             for (int j = 0; j < KPT; ++j)
                 if ((uint32_t)j < kp) e[j] = s_elems[seg + (uint32_t)j * WAVE];
             // (the next scatter into s_elems comes two barriers later)
         }
+#ifdef RSX_B16_TIMING
+        __syncthreads();
+#endif
+        RSX_PTICK(3)
     }
-    for (uint32_t i = tid; i < n; i += WG) {
-        E x = s_elems[i];
+}
+
+// s_elems[0, n) -> dst[0, n)
+template <int ES, int KPT, int WG>
+__device__ __forceinline__ void local_store(const SmallArgs& a, Elem<ES>* __restrict__ dst, const uint32_t n, unsigned char* smem) {
+    const Elem<ES>* s_elems = reinterpret_cast<const Elem<ES>*>(smem);
+    for (uint32_t i = threadIdx.x; i < n; i += WG) {
+        Elem<ES> x = s_elems[i];
         if (a.map_store) key_map<ES, true>(x, a.xf);
         dst[i] = x;
     }
+}
+
+// Sorts elements [0, n) of `src` by `a.passes` digits into `dst` (same index range), n <= WG * KPT.
+template <int ES, int KPT, int WG>
+__device__ __forceinline__ void local_sort(const SmallArgs& a, const Elem<ES>* __restrict__ src, Elem<ES>* __restrict__ dst,
+                                           const uint32_t n, unsigned char* smem) {
+    Elem<ES> e[KPT];
+    local_load<ES, KPT, WG>(a, src, n, e);
+    local_passes<ES, KPT, WG>(a, e, n, smem);
+    local_store<ES, KPT, WG>(a, dst, n, smem);
 }
 
 // A bucket LARGER than a workgroup holds (the host predicted a spread-out top digit from the previous sort's counts and
@@ -297,27 +344,189 @@ __global__ __launch_bounds__(WG) void rsx_bucket_sort_kernel(const SmallArgs a) 
                               (uint32_t)count, smem);
 }
 
+// waves per SIMD the bucket16 kernel is compiled for: its LDS lets 2 workgroups of 512 threads (4 waves per SIMD) or 3
+// of 256 (3 waves per SIMD) share a CU, if their registers do
+#define RSX_B16_WAVES(WG) ((WG) >= 512 ? 4 : 3)
 // Wide keys, large arrays (rsx_mid_kernels.hpp, rsx_count16top_kernel): the array is partitioned by the top 16 bits of
 // the mapped key; starts[b] .. starts[b + 1] is bucket b.  Persistent workgroups take the buckets round-robin and sort
 // each by the remaining digits in LDS, in place; one that does not fit goes through memory (`scratch`, same offsets).
 // WG: 1024 threads (one workgroup per CU), or 256 where the average bucket fits a quarter of that: three workgroups per
 // CU then work on three buckets at once (2^28 u64 keys: the buckets hold 4096).
+// After local_passes(first = f > 0) the array in LDS is sorted by digits f .. passes-1 only, elements that agree on
+// those in input order.  Where neighbours agree (a "run"), the skipped digits 0 .. f-1 decide.
+// agree(): on the key bits from digit f up (a.cmp_mask, built by the host).
+template <int ES>
+__device__ __forceinline__ bool agree(const SmallArgs& a, const Elem<ES>& x, const Elem<ES>& y) {
+    uint32_t diff = 0;
+#pragma unroll
+    for (int w = 0; w < ES / 4; ++w) diff |= (x.w[w] ^ y.w[w]) & a.cmp_mask[w];
+    return diff == 0;
+}
+// One thread per run sorts it by the skipped digits (stable insertion).  Returns false (for every thread) if some run
+// is too long for that -- the caller then runs all passes on what LDS holds (a stable sort of a permutation whose equal
+// keys are in input order).  Rare: local_finish only comes here when some neighbours agree.
+template <int ES, int WG>
+__device__ __forceinline__ bool local_mend(const SmallArgs& a, const uint32_t n, unsigned char* smem, const uint32_t f, uint32_t* s_flag) {
+    using E = Elem<ES>;
+    constexpr uint32_t MAX_RUN = 48;
+    E* s_elems = reinterpret_cast<E*>(smem);
+    auto less = [&](const E& x, const E& y) {  // by digits f-1 .. 0
+        for (uint32_t d = f; d-- > 0;) {
+            const uint32_t dx = elem_digit<ES, false>(x, a.spec[d]), dy = elem_digit<ES, false>(y, a.spec[d]);
+            if (dx != dy) return dx < dy;
+        }
+        return false;
+    };
+    if (threadIdx.x == 0) *s_flag = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i + 1 < n; i += WG) {
+        if (i != 0 && agree<ES>(a, s_elems[i], s_elems[i - 1])) continue;  // not the head of a run
+        if (!agree<ES>(a, s_elems[i + 1], s_elems[i])) continue;           // a run of one
+        uint32_t len = 2;
+        while (i + len < n && len <= MAX_RUN && agree<ES>(a, s_elems[i + len], s_elems[i])) ++len;
+        if (len > MAX_RUN) {
+            *s_flag = 1;
+            continue;
+        }
+        for (uint32_t k = 1; k < len; ++k) {  // stable insertion by the skipped digits
+            const E x = s_elems[i + k];
+            uint32_t j = k;
+            while (j > 0 && less(x, s_elems[i + j - 1])) {
+                s_elems[i + j] = s_elems[i + j - 1];
+                --j;
+            }
+            s_elems[i + j] = x;
+        }
+    }
+    __syncthreads();
+    return *s_flag == 0;
+}
+
+// The end of a bucket whose passes started at digit f > 0: the sorted tile is read back in store order together with
+// every element's predecessor (local_check; true if some neighbours agree); if none do -- the rule -- the registers go
+// straight to memory (local_store_regs).
 template <int ES, int KPT, int WG>
-__global__ __launch_bounds__(WG) void rsx_bucket16_kernel(const SmallArgs a, const uint64_t* __restrict__ starts, void* scratch, Gate gate) {
+__device__ __forceinline__ bool local_check(const SmallArgs& a, const uint32_t n, unsigned char* smem, Elem<ES> (&x)[KPT]) {
+    using E = Elem<ES>;
+    const E* s_elems = reinterpret_cast<const E*>(smem);
+    uint32_t ties = 0;  // (no short-circuit: the reads of all rounds are in flight together)
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const uint32_t i = (uint32_t)j * WG + threadIdx.x;
+        x[j] = E{};
+        if (i < n) {
+            x[j] = s_elems[i];
+            const E p = s_elems[i != 0 ? i - 1 : 0];
+            uint32_t diff = 0;
+#pragma unroll
+            for (int w = 0; w < ES / 4; ++w) diff |= (x[j].w[w] ^ p.w[w]) & a.cmp_mask[w];
+            ties |= (diff == 0 && i != 0) ? 1u : 0u;
+        }
+    }
+    return __syncthreads_or(ties != 0 ? 1 : 0) != 0;
+}
+template <int ES, int KPT, int WG>
+__device__ __forceinline__ void local_store_regs(const SmallArgs& a, Elem<ES>* __restrict__ dst, const uint32_t n, Elem<ES> (&x)[KPT]) {
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const uint32_t i = (uint32_t)j * WG + threadIdx.x;
+        if (i < n) {
+            if (a.map_store) key_map<ES, true>(x[j], a.xf);
+            dst[i] = x[j];
+        }
+    }
+}
+
+// false: the runs could not be mended (nothing stored)
+template <int ES, int KPT, int WG>
+__device__ __forceinline__ bool local_finish(const SmallArgs& a, Elem<ES>* __restrict__ dst, const uint32_t n, unsigned char* smem, const uint32_t f,
+                                             uint32_t* s_flag) {
+    Elem<ES> x[KPT];
+    if (!local_check<ES, KPT, WG>(a, n, smem, x)) {
+        local_store_regs<ES, KPT, WG>(a, dst, n, x);
+        return true;
+    }
+    if (!local_mend<ES, WG>(a, n, smem, f, s_flag)) return false;
+    local_store<ES, KPT, WG>(a, dst, n, smem);
+    return true;
+}
+
+template <int ES, int KPT, int WG>
+__global__ __launch_bounds__(WG, RSX_B16_WAVES(WG)) void rsx_bucket16_kernel(const SmallArgs a, const uint64_t* __restrict__ starts, void* scratch,
+                                                                         Gate gate) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (!gate_open(gate)) return;
+    using E = Elem<ES>;
+    constexpr int NWAVE = WG / WAVE;
+    uint32_t* s_flag = reinterpret_cast<uint32_t*>(smem + (size_t)WG * KPT * sizeof(E)) + NWAVE * RADIX + NWAVE;  // (s_misc is [NWAVE]; 16 words there)
+    // A bucket of m elements that agree on their top 16 bits is, as a rule, told apart by the next 2 log2(m) bits or so:
+    // the passes start at the digit that leaves four (32 bits for at most 2^15 elements), the neighbours that still
+    // agree afterwards are put right one run at a time (local_mend), and a workgroup that meets an input where that
+    // does not work -- long runs: few distinct values in those 32 bits -- runs all passes from then on.
+    uint32_t skip = (a.passes > 4 && !a.no_skip) ? a.passes - 4 : 0;
+#ifdef RSX_B16_TIMING
+    uint64_t tm[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t nb_done = 0;
+#define RSX_TICK(k)                          \
+    {                                        \
+        __syncthreads();                     \
+        const uint64_t now = wall_clock64(); \
+        tm[k] += now - t_prev;               \
+        t_prev = now;                        \
+    }
+#else
+#define RSX_TICK(k)
+#endif
+    // (Requesting the next bucket ahead of this one's check and store -- its registers are free after the last scatter --
+    // would cover a 4.6 us round trip of 31 per bucket on 2^30 u64, but every form of that loop tried spilled 50-370
+    // registers and ran slower.)
     for (uint32_t b = blockIdx.x; b < 65536u; b += gridDim.x) {
+#ifdef RSX_B16_TIMING
+        uint64_t t_prev = wall_clock64();
+#endif
         const uint64_t start = starts[b];
         const uint64_t count = starts[b + 1] - start;  // (the same for every thread: uniform control flow below)
         if (count == 0) continue;
-        Elem<ES>* bucket = static_cast<Elem<ES>*>(a.data) + start;
+        E* bucket = static_cast<E*>(a.data) + start;
         if (count > (uint64_t)WG * KPT) {  // an even number of passes: ends where it began
-            big_bucket_sort<ES, KPT, WG>(a, bucket, static_cast<Elem<ES>*>(scratch) + start, (uint32_t)count, smem);
+            big_bucket_sort<ES, KPT, WG>(a, bucket, static_cast<E*>(scratch) + start, (uint32_t)count, smem);
         } else {
-            local_sort<ES, KPT, WG>(a, bucket, bucket, (uint32_t)count, smem);
+            const uint32_t n = (uint32_t)count;
+            E e[KPT];
+            local_load<ES, KPT, WG>(a, bucket, n, e);
+#ifdef RSX_B16_TIMING
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            RSX_TICK(1)
+            local_passes<ES, KPT, WG>(a, e, n, smem, skip);
+            RSX_TICK(2)
+            if (skip == 0) {
+                local_store<ES, KPT, WG>(a, bucket, n, smem);
+            } else if (!local_finish<ES, KPT, WG>(a, bucket, n, smem, skip, s_flag)) {
+                skip = 0;  // runs too long to mend: every pass, on what LDS holds, and from now on
+                const uint32_t kp = (n + WG - 1) / WG, seg = (threadIdx.x >> 6) * (WAVE * kp) + (threadIdx.x & 63u);
+#pragma unroll
+                for (int j = 0; j < KPT; ++j)
+                    if ((uint32_t)j < kp) e[j] = reinterpret_cast<const E*>(smem)[seg + (uint32_t)j * WAVE];
+                __syncthreads();
+                local_passes<ES, KPT, WG>(a, e, n, smem, 0);
+                local_store<ES, KPT, WG>(a, bucket, n, smem);
+            }
+            RSX_TICK(3)
+#ifdef RSX_B16_TIMING
+            ++nb_done;
+#endif
         }
         __syncthreads();  // smem belongs to the next bucket
     }
+#ifdef RSX_B16_TIMING
+    if (blockIdx.x == 7 && threadIdx.x == 0)
+        printf("   passes: rank %llu scan %llu scatter %llu readback %llu (x10 ns)\n", g_ptm[0], g_ptm[1], g_ptm[2], g_ptm[3]);
+    if (blockIdx.x == 7 && threadIdx.x == 0)
+        printf("b16 ES=%d WG=%d buckets %u: - %llu wait-for-load %llu passes %llu check+store %llu - %llu - %llu (x10 ns)\n", ES, WG, nb_done,
+               (unsigned long long)tm[0], (unsigned long long)tm[1], (unsigned long long)tm[2], (unsigned long long)tm[3],
+               (unsigned long long)tm[4], (unsigned long long)tm[5]);
+#endif
 }
 
 }  // namespace rsx

@@ -135,13 +135,15 @@ def test_wide_key_hybrid_forced(rs, torch, orc, t):
     c = rs.Context(torch.cuda.current_device())
     c.set_option(rs.OPT_WIDE_SORT, 2)
     rng = np.random.default_rng(31 + d.elem_bytes)
-    for i, dist in enumerate(util.DISTS):
-        n = int(rng.integers(70000, 400000))
-        raw = util.make_input(t, n, dist, seed=300 + i)
-        x = torch.from_numpy(raw.copy()).cuda()
-        rs.radix_sort(x, digits=d, ctx=c)
-        c.check()
-        assert np.array_equal(x.cpu().numpy(), orc.sort_parallel(raw, lay, 8)), (t, n, dist)
+    for skip in (1, 0):  # LDS passes from the digit that leaves four + mending of the runs that still agree / every pass
+        c.set_option(rs.OPT_BUCKET_SKIP, skip)
+        for i, dist in enumerate(util.DISTS):
+            n = int(rng.integers(70000, 400000))
+            raw = util.make_input(t, n, dist, seed=300 + i)
+            x = torch.from_numpy(raw.copy()).cuda()
+            rs.radix_sort(x, digits=d, ctx=c)
+            c.check()
+            assert np.array_equal(x.cpu().numpy(), orc.sort_parallel(raw, lay, 8)), (t, n, dist, skip)
     c.close()
 
 
@@ -167,6 +169,42 @@ def test_wide_key_hybrid_counts_from_the_16_bit_counters(rs, torch, orc, t):
         assert np.array_equal(x.cpu().numpy(), orc.sort_parallel(raw, lay, 8)), (t, n, dist)
         if path == 0:
             c.set_option(rs.OPT_WIDE_SORT, 3)  # (a refusal is followed by 15 sorts without a try: start over)
+    c.close()
+
+
+@pytest.mark.parametrize("t", ["u64", "i64", "f64", "(u64,u64)", "u128", "(u128,u128)"])
+def test_wide_key_hybrid_mends_the_runs_its_passes_left(rs, torch, orc, t):
+    """The hybrid's LDS passes start at the digit that leaves four; neighbours that still agree afterwards are put right
+    by the skipped digits.  Inputs made for that: (A) many short runs -- elements that share everything but their low 16
+    bits with a neighbour; (B) whole buckets that agree on everything between the top and the low 16 bits (runs too long
+    to mend: the workgroup runs every pass); then uniform keys again.  Payload = index, so stability shows."""
+    d = _digits(rs, t)
+    es, ko, kb, _kind = util.TYPES[t]
+    lay = orc.Layout(*util.TYPES[t])
+    c = rs.Context(torch.cuda.current_device())
+    c.set_option(rs.OPT_WIDE_SORT, 3)
+    n = _mid_max(es) + 300001
+    rng = np.random.default_rng(4242 + es + kb)
+    idx = np.arange(n, dtype=np.uint64).view(np.uint8).reshape(n, 8)
+    for case in ("A", "B", "uniform"):
+        raw = np.zeros((n, es), dtype=np.uint8)
+        key = rng.integers(0, 256, size=(n, kb), dtype=np.uint8)
+        if case == "A":
+            pick = np.flatnonzero(rng.random(n) < 0.4)
+            pick = pick[pick > 0]
+            for _ in range(3):  # chains: runs of up to four
+                key[pick, 2:] = key[pick - 1, 2:]
+        elif case == "B":
+            key[:, 2:kb - 2] = 0
+        raw[:, ko:ko + kb] = key
+        for j, b in enumerate(b for b in range(es) if not ko <= b < ko + kb):
+            raw[:, b] = idx[:, j] if j < 8 else 0
+        x = torch.from_numpy(raw.reshape(-1).copy()).cuda()
+        rs.radix_sort(x, digits=d, ctx=c)
+        c.check()
+        info = c.get_info(rs.INFO_LAST_PASSES)
+        assert (info >> 24) & 15 == 5, (t, case, hex(info))
+        assert np.array_equal(x.cpu().numpy(), orc.sort_parallel(raw.reshape(-1), lay, 8)), (t, case)
     c.close()
 
 

@@ -28,5 +28,5 @@ for t in types:
                 if it >= 2: tot += e0.elapsed_time(e1)
             res.append(tot / 4)
             ctx.close()
-        print(f"{t} 2^{lg}: LSD {res[0]:8.3f} ms  hybrid {res[1]:8.3f} ms  x{res[0]/res[1]:.2f}  ({n/res[1]/1e6:.1f} Gkeys/s)", flush=True)
+        print(f"{t} 2^{lg}: " + "  ".join(f"mode {m}: {r:8.3f} ms ({n/r/1e6:.1f} Gkeys/s)" for m, r in zip(MODES, res)) + (f"  x{res[0]/res[-1]:.2f}" if len(res) > 1 else ""), flush=True)
         del x, tmp
