@@ -142,7 +142,7 @@ def run_single(rs, torch, ctx, wl, steps, warmup, seed0=0x5EED0000, profile=True
     if profile and prof_tot["sweep"][1]:
         # wide-key hybrid: both kernel sequences are enqueued and the device runs one (the other's launches return at
         # once, ~5 us each, and are inside these sums): per sort 2 real sweeps, 1 bucket kernel, 1 count + 1 marginal
-        real = 2 * steps if path == 5 else prof_tot["sweep"][1]
+        real = 2 * steps if path == 5 else D * steps if path == 0 and prof_tot["sweep"][1] > D * steps else prof_tot["sweep"][1]
         sw_ms = prof_tot["sweep"][0] / real
         res["sweep_ms_per_launch"] = sw_ms
         res["sweep_launches"] = real
@@ -262,8 +262,10 @@ def roofline_of(res, workload, n, d):
         "hbm_bytes_per_launch_by_design": 2 * n * d.elem_bytes,
         "hbm_gbps_by_design": res["bucket_hbm_gbps"], "hbm_frac_by_design": res["bucket_hbm_gbps"] / HBM_PEAK_GBPS,
         "traffic": pmc_traffic(workload, "bucket16"),
-        "note": "frac counts the algorithm's bytes for the digit passes this launch performs; it can exceed 1 because they "
-                "run in LDS (the kernel reads and writes the array once: hbm_*_by_design, traffic = rocprofv3 PMC)",
+        "note": "frac counts the algorithm's bytes (2*n*s per digit pass, SURVEY 8(d)) for the D-2 passes this launch stands for; "
+                "it can exceed 1 because they run in LDS -- and only the top four of them are run, the neighbours that still "
+                "agree afterwards are mended by the skipped digits -- while the kernel reads and writes the array once "
+                "(hbm_*_by_design; traffic = rocprofv3 PMC)",
         "per_sort_ms": {"count16 + marginal": res.get("count16_ms_per_sort"), "total16 + scan16": res.get("scan16_ms_per_sort"),
                         "sweeps (2)": 2 * res["sweep_ms_per_launch"], "bucket16": res["bucket_ms_per_launch"]},
         "sweep": sweep,

@@ -349,12 +349,16 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
     // once costs ~5 us: nothing beside milliseconds).  A refused try costs its count (one read of the array): the
     // verdict is also written host-visibly, and after a refusal the context goes 15 sorts without trying.
     const uint32_t es = L->elem_bytes;
-    const bool wide_type = ctx->wide_mode >= 2 ? (es >= 4 && D >= 4) : (es >= 8 && D >= 8);
+    // Where it pays (measured, uniform keys, hybrid / LSD passes): u64 x1.25 at 2^26, x1.6-1.8 from 2^27 on; (u64,u64)
+    // x1.1 at 2^24, x1.9 from 2^26; u128 x1.5 at 2^23, x3.7 from 2^26; (u32,u32) x1.2 from 2^28 (two of four passes in
+    // LDS).  Below those sizes its fixed costs (65536 buckets, ~0.6 ms) lose against the plain passes.
+    const bool wide_type = es >= 8 && D >= 4;
+    const size_t wide_floor = D >= 16 ? ((size_t)128 << 20) : D >= 8 ? (es >= 16 ? ((size_t)256 << 20) : ((size_t)512 << 20)) : ((size_t)2 << 30);
     const bool wide_size = wide_type && (uint64_t)n > mid_max_for(es);
     bool wide = false;
     if (ctx->wide_mode == 2) {
         wide = wide_type && n >= 65536;
-    } else if (((ctx->wide_mode == 1 && n * (size_t)es >= ((size_t)2 << 30)) || ctx->wide_mode == 3) && wide_size &&
+    } else if (((ctx->wide_mode == 1 && n * (size_t)es >= wide_floor) || ctx->wide_mode == 3) && wide_size &&
                (uint64_t)n / 65536u < (uint64_t)bucket_cap_for(es)) {  // (the real test is the device's, on the actual counts)
         volatile uint32_t* hint = reinterpret_cast<volatile uint32_t*>(ctx->host_err) + 9;  // the last try's verdict: 1 taken, 2 refused
         if (ctx->wide_skip > 0) {

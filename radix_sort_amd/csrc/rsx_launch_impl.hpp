@@ -306,6 +306,14 @@ int launch_mid_split(rsx_ctx* ctx, const void* src, void* dst, size_t n, const r
 }
 
 // ---- ... then the 256 buckets, each sorted by one workgroup --------------------------------------
+// the bucket kernels start their LDS passes at digit passes - 4 (RSX_OPT_BUCKET_SKIP) and compare neighbours on the key
+// bytes from there up
+inline void set_skip_mask(rsx_ctx* ctx, SmallArgs& a, const rsx_layout* L) {
+    a.no_skip = ctx->bucket_no_skip;
+    if (a.passes > 4 && !a.no_skip)
+        for (uint32_t byte = L->key_offset + a.passes - 4; byte < L->key_offset + L->key_bytes; ++byte) a.cmp_mask[byte >> 2] |= 0xFFu << (8 * (byte & 3));
+}
+
 template <int ES>
 int launch_bucket_sort(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L, hipStream_t st) {
     if constexpr (ES == 1) {
@@ -330,6 +338,7 @@ int launch_bucket_sort(rsx_ctx* ctx, const void* src, void* dst, const RegionGeo
         a.top_tot = mid_totals_of(ctx);
         a.cap = bucket_cap(ES);
         a.hint = ctx->host_err_dev + 8;
+        set_skip_mask(ctx, a, L);
         LaunchTimer lt(ctx, RSX_PROF_OTHER, st);
         if (ctx->bucket_small) {  // small buckets, all known to fit: 256 threads each
             const size_t lds = (size_t)256 * KPT * ES + 4 * RADIX * sizeof(uint32_t) + 64 + 3 * RADIX * sizeof(uint32_t);
@@ -410,9 +419,7 @@ int launch_bucket16(rsx_ctx* ctx, void* data, void* scratch, size_t n, const rsx
         }
         a.xf = make_xform(L);
         a.cap = bucket_cap(ES);
-        a.no_skip = ctx->bucket_no_skip;
-        if (a.passes > 4 && !a.no_skip)  // (rsx_bucket16_kernel starts at digit passes - 4: the key bytes from there up)
-            for (uint32_t byte = L->key_offset + a.passes - 4; byte < L->key_offset + L->key_bytes; ++byte) a.cmp_mask[byte >> 2] |= 0xFFu << (8 * (byte & 3));
+        set_skip_mask(ctx, a, L);
         LaunchTimer lt(ctx, RSX_PROF_OTHER, st);
         // workgroup size by the AVERAGE bucket (a few buckets above the capacity go through memory): 256, 512 or 1024
         // threads x KPT elements, as many workgroups per CU as their LDS allows (3-4, 2, 1)

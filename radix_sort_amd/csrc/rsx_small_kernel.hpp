@@ -38,9 +38,6 @@ struct SmallArgs {
                                       // 256-thread workgroup, 3 = a 1024-thread one, 2 = some bucket fits neither
 };
 
-#ifdef RSX_B16_TIMING
-__device__ unsigned long long g_ptm[8];
-#endif
 // The elements of a workgroup's array [0, n) as its threads hold them: wave w holds [w*64*kp, (w+1)*64*kp), round j at
 // +j*64 -- (wave, round, lane) order == index order, so ranks are stable.  kp = ceil(n / WG) rounds are in use.
 template <int ES, int KPT, int WG>
@@ -74,20 +71,8 @@ __device__ __forceinline__ void local_passes(const SmallArgs& a, Elem<ES> (&e)[K
     const uint32_t kp = (n + WG - 1) / WG;          // rounds in use, 1..KPT (wave-uniform, the same for all)
     const uint32_t seg = wave * (WAVE * kp) + lane;
     uint32_t* my = s_cnt + wave * RADIX;
-#ifdef RSX_B16_TIMING
-    uint64_t pt = wall_clock64();
-#define RSX_PTICK(k)                                              \
-    {                                                             \
-        const uint64_t now = wall_clock64();                      \
-        if (blockIdx.x == 7 && tid == 0) g_ptm[k] += now - pt;    \
-        pt = now;                                                 \
-    }
-#else
-#define RSX_PTICK(k)
-#endif
     for (uint32_t pass = first; pass < a.passes; ++pass) {
         const DigitSpec spec = a.spec[pass];
-        RSX_PTICK(5)
 #pragma unroll
         for (int i = 0; i < RADIX / WAVE; ++i) my[i * WAVE + lane] = 0;
         // the slots past n are padding: digit 255, and being the highest indices they rank behind every real 255
@@ -112,7 +97,6 @@ __device__ __forceinline__ void local_passes(const SmallArgs& a, Elem<ES> (&e)[K
             }
         }
         __syncthreads();
-        RSX_PTICK(0)
         // count -> prefix: start of (digit v, wave w) in the sorted tile, digit-major / wave-minor
         uint32_t tcount = 0, incl = 0;
         if (tid < RADIX) {
@@ -133,22 +117,16 @@ __device__ __forceinline__ void local_passes(const SmallArgs& a, Elem<ES> (&e)[K
             }
         }
         __syncthreads();
-        RSX_PTICK(1)
 #pragma unroll
         for (int j = 0; j < KPT; ++j)
             if ((uint32_t)j < kp) s_elems[my[digit_of(j)] + rk[j]] = e[j];
         __syncthreads();
-        RSX_PTICK(2)
         if (pass + 1 < a.passes) {
 #pragma unroll
             for (int j = 0; j < KPT; ++j)
                 if ((uint32_t)j < kp) e[j] = s_elems[seg + (uint32_t)j * WAVE];
             // (the next scatter into s_elems comes two barriers later)
         }
-#ifdef RSX_B16_TIMING
-        __syncthreads();
-#endif
-        RSX_PTICK(3)
     }
 }
 
@@ -292,58 +270,6 @@ __device__ void big_bucket_sort(const SmallArgs& a, Elem<ES>* buf0, Elem<ES>* bu
     }
 }
 
-template <int ES, int KPT>
-__global__ __launch_bounds__(512) void rsx_small_sort_kernel(const SmallArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    local_sort<ES, KPT, 512>(a, static_cast<const Elem<ES>*>(a.src), static_cast<Elem<ES>*>(a.data), a.n, smem);
-}
-
-// grid = 256: workgroup v sorts the bucket of top-digit value v, [start_v, start_v + count_v) of the partitioned
-// array, by the lower digits.  The bucket's place comes from the 256 totals of the top digit.
-// WG: 1024 threads, or 256 for small buckets (n / 256 <= 2048 and the forecast says they all fit 256 x KPT): fewer
-// waves to scan and to wait for at the barriers -- 2^16 u32 keys 15.9 -> ~10 us.
-template <int ES, int KPT, int WG>
-__global__ __launch_bounds__(WG) void rsx_bucket_sort_kernel(const SmallArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t* s_red = reinterpret_cast<uint64_t*>(smem);  // [0..3] partial sums, [4] the bucket's count, [5..8] partial maxima
-    const uint32_t tid = threadIdx.x, v = blockIdx.x;
-    uint64_t c = 0;
-    if (tid < RADIX) {
-        c = a.top_tot[tid];
-        if (tid == v) s_red[4] = c;
-        if (v == 0) {  // workgroup 0 reports the largest bucket
-            uint64_t big = c;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const uint64_t y = __shfl_xor(big, o);
-                big = y > big ? y : big;
-            }
-            if ((tid & 63u) == 0u) s_red[5 + (tid >> 6)] = big;
-        }
-        uint64_t below = tid < v ? c : 0ull;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o);
-        if ((tid & 63u) == 0u) s_red[tid >> 6] = below;
-    }
-    __syncthreads();
-    const uint64_t start = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-    const uint64_t count = s_red[4];
-    if (v == 0 && tid == 0) {
-        uint64_t big = s_red[5];
-        for (int w = 1; w < 4; ++w) big = s_red[5 + w] > big ? s_red[5 + w] : big;
-        __hip_atomic_store(a.hint, big <= (uint64_t)a.cap / 4 ? 1u : big <= (uint64_t)a.cap ? 3u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    __syncthreads();  // smem is the sort's from here
-    if (count == 0) return;
-    if (count > (uint64_t)WG * KPT) {  // a skewed top digit the host did not foresee: through memory, by this workgroup alone
-        big_bucket_sort<ES, KPT, WG>(a, const_cast<Elem<ES>*>(static_cast<const Elem<ES>*>(a.src)) + start,
-                                     static_cast<Elem<ES>*>(a.data) + start, (uint32_t)count, smem);
-        return;
-    }
-    local_sort<ES, KPT, WG>(a, static_cast<const Elem<ES>*>(a.src) + start, static_cast<Elem<ES>*>(a.data) + start,
-                              (uint32_t)count, smem);
-}
-
 // waves per SIMD the bucket16 kernel is compiled for: its LDS lets 2 workgroups of 512 threads (4 waves per SIMD) or 3
 // of 256 (3 waves per SIMD) share a CU, if their registers do
 #define RSX_B16_WAVES(WG) ((WG) >= 512 ? 4 : 3)
@@ -451,6 +377,88 @@ __device__ __forceinline__ bool local_finish(const SmallArgs& a, Elem<ES>* __res
     return true;
 }
 
+// One array of at most WG * KPT elements, src -> dst: the passes from digit `skip` on, the check, the mending or -- if the
+// runs are too long for that -- every pass (and skip = 0 for the caller's later arrays).
+template <int ES, int KPT, int WG>
+__device__ __forceinline__ void local_sort_skip(const SmallArgs& a, const Elem<ES>* __restrict__ src, Elem<ES>* __restrict__ dst, const uint32_t n,
+                                                unsigned char* smem, uint32_t& skip, uint32_t* s_flag) {
+    using E = Elem<ES>;
+    if constexpr (ES < 8) {  // (keys of more than five bytes only: narrower elements never skip)
+        local_sort<ES, KPT, WG>(a, src, dst, n, smem);
+        return;
+    }
+    E e[KPT];
+    local_load<ES, KPT, WG>(a, src, n, e);
+    local_passes<ES, KPT, WG>(a, e, n, smem, skip);
+    if (skip == 0) {
+        local_store<ES, KPT, WG>(a, dst, n, smem);
+    } else if (!local_finish<ES, KPT, WG>(a, dst, n, smem, skip, s_flag)) {
+        skip = 0;
+        const uint32_t kp = (n + WG - 1) / WG, seg = (threadIdx.x >> 6) * (WAVE * kp) + (threadIdx.x & 63u);
+#pragma unroll
+        for (int j = 0; j < KPT; ++j)
+            if ((uint32_t)j < kp) e[j] = reinterpret_cast<const E*>(smem)[seg + (uint32_t)j * WAVE];
+        __syncthreads();
+        local_passes<ES, KPT, WG>(a, e, n, smem, 0);
+        local_store<ES, KPT, WG>(a, dst, n, smem);
+    }
+}
+
+template <int ES, int KPT>
+__global__ __launch_bounds__(512) void rsx_small_sort_kernel(const SmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    local_sort<ES, KPT, 512>(a, static_cast<const Elem<ES>*>(a.src), static_cast<Elem<ES>*>(a.data), a.n, smem);
+}
+
+// grid = 256: workgroup v sorts the bucket of top-digit value v, [start_v, start_v + count_v) of the partitioned
+// array, by the lower digits.  The bucket's place comes from the 256 totals of the top digit.
+// WG: 1024 threads, or 256 for small buckets (n / 256 <= 2048 and the forecast says they all fit 256 x KPT): fewer
+// waves to scan and to wait for at the barriers -- 2^16 u32 keys 15.9 -> ~10 us.
+template <int ES, int KPT, int WG>
+__global__ __launch_bounds__(WG) void rsx_bucket_sort_kernel(const SmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* s_red = reinterpret_cast<uint64_t*>(smem);  // [0..3] partial sums, [4] the bucket's count, [5..8] partial maxima
+    const uint32_t tid = threadIdx.x, v = blockIdx.x;
+    uint64_t c = 0;
+    if (tid < RADIX) {
+        c = a.top_tot[tid];
+        if (tid == v) s_red[4] = c;
+        if (v == 0) {  // workgroup 0 reports the largest bucket
+            uint64_t big = c;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint64_t y = __shfl_xor(big, o);
+                big = y > big ? y : big;
+            }
+            if ((tid & 63u) == 0u) s_red[5 + (tid >> 6)] = big;
+        }
+        uint64_t below = tid < v ? c : 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o);
+        if ((tid & 63u) == 0u) s_red[tid >> 6] = below;
+    }
+    __syncthreads();
+    const uint64_t start = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    const uint64_t count = s_red[4];
+    if (v == 0 && tid == 0) {
+        uint64_t big = s_red[5];
+        for (int w = 1; w < 4; ++w) big = s_red[5 + w] > big ? s_red[5 + w] : big;
+        __hip_atomic_store(a.hint, big <= (uint64_t)a.cap / 4 ? 1u : big <= (uint64_t)a.cap ? 3u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();  // smem is the sort's from here
+    if (count == 0) return;
+    if (count > (uint64_t)WG * KPT) {  // a skewed top digit the host did not foresee: through memory, by this workgroup alone
+        big_bucket_sort<ES, KPT, WG>(a, const_cast<Elem<ES>*>(static_cast<const Elem<ES>*>(a.src)) + start,
+                                     static_cast<Elem<ES>*>(a.data) + start, (uint32_t)count, smem);
+        return;
+    }
+    // (as in rsx_bucket16_kernel: the passes start at the digit that leaves four, neighbours that still agree are mended)
+    uint32_t skip = (a.passes > 4 && !a.no_skip) ? a.passes - 4 : 0;
+    uint32_t* s_flag = reinterpret_cast<uint32_t*>(smem + (size_t)WG * KPT * sizeof(Elem<ES>)) + (WG / WAVE) * RADIX + (WG / WAVE);
+    local_sort_skip<ES, KPT, WG>(a, static_cast<const Elem<ES>*>(a.src) + start, static_cast<Elem<ES>*>(a.data) + start, (uint32_t)count, smem,
+                                 skip, s_flag);
+}
+
 template <int ES, int KPT, int WG>
 __global__ __launch_bounds__(WG, RSX_B16_WAVES(WG)) void rsx_bucket16_kernel(const SmallArgs a, const uint64_t* __restrict__ starts, void* scratch,
                                                                          Gate gate) {
@@ -464,26 +472,10 @@ __global__ __launch_bounds__(WG, RSX_B16_WAVES(WG)) void rsx_bucket16_kernel(con
     // agree afterwards are put right one run at a time (local_mend), and a workgroup that meets an input where that
     // does not work -- long runs: few distinct values in those 32 bits -- runs all passes from then on.
     uint32_t skip = (a.passes > 4 && !a.no_skip) ? a.passes - 4 : 0;
-#ifdef RSX_B16_TIMING
-    uint64_t tm[6] = {0, 0, 0, 0, 0, 0};
-    uint32_t nb_done = 0;
-#define RSX_TICK(k)                          \
-    {                                        \
-        __syncthreads();                     \
-        const uint64_t now = wall_clock64(); \
-        tm[k] += now - t_prev;               \
-        t_prev = now;                        \
-    }
-#else
-#define RSX_TICK(k)
-#endif
     // (Requesting the next bucket ahead of this one's check and store -- its registers are free after the last scatter --
     // would cover a 4.6 us round trip of 31 per bucket on 2^30 u64, but every form of that loop tried spilled 50-370
     // registers and ran slower.)
     for (uint32_t b = blockIdx.x; b < 65536u; b += gridDim.x) {
-#ifdef RSX_B16_TIMING
-        uint64_t t_prev = wall_clock64();
-#endif
         const uint64_t start = starts[b];
         const uint64_t count = starts[b + 1] - start;  // (the same for every thread: uniform control flow below)
         if (count == 0) continue;
@@ -491,42 +483,10 @@ __global__ __launch_bounds__(WG, RSX_B16_WAVES(WG)) void rsx_bucket16_kernel(con
         if (count > (uint64_t)WG * KPT) {  // an even number of passes: ends where it began
             big_bucket_sort<ES, KPT, WG>(a, bucket, static_cast<E*>(scratch) + start, (uint32_t)count, smem);
         } else {
-            const uint32_t n = (uint32_t)count;
-            E e[KPT];
-            local_load<ES, KPT, WG>(a, bucket, n, e);
-#ifdef RSX_B16_TIMING
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-            RSX_TICK(1)
-            local_passes<ES, KPT, WG>(a, e, n, smem, skip);
-            RSX_TICK(2)
-            if (skip == 0) {
-                local_store<ES, KPT, WG>(a, bucket, n, smem);
-            } else if (!local_finish<ES, KPT, WG>(a, bucket, n, smem, skip, s_flag)) {
-                skip = 0;  // runs too long to mend: every pass, on what LDS holds, and from now on
-                const uint32_t kp = (n + WG - 1) / WG, seg = (threadIdx.x >> 6) * (WAVE * kp) + (threadIdx.x & 63u);
-#pragma unroll
-                for (int j = 0; j < KPT; ++j)
-                    if ((uint32_t)j < kp) e[j] = reinterpret_cast<const E*>(smem)[seg + (uint32_t)j * WAVE];
-                __syncthreads();
-                local_passes<ES, KPT, WG>(a, e, n, smem, 0);
-                local_store<ES, KPT, WG>(a, bucket, n, smem);
-            }
-            RSX_TICK(3)
-#ifdef RSX_B16_TIMING
-            ++nb_done;
-#endif
+            local_sort_skip<ES, KPT, WG>(a, bucket, bucket, (uint32_t)count, smem, skip, s_flag);
         }
         __syncthreads();  // smem belongs to the next bucket
     }
-#ifdef RSX_B16_TIMING
-    if (blockIdx.x == 7 && threadIdx.x == 0)
-        printf("   passes: rank %llu scan %llu scatter %llu readback %llu (x10 ns)\n", g_ptm[0], g_ptm[1], g_ptm[2], g_ptm[3]);
-    if (blockIdx.x == 7 && threadIdx.x == 0)
-        printf("b16 ES=%d WG=%d buckets %u: - %llu wait-for-load %llu passes %llu check+store %llu - %llu - %llu (x10 ns)\n", ES, WG, nb_done,
-               (unsigned long long)tm[0], (unsigned long long)tm[1], (unsigned long long)tm[2], (unsigned long long)tm[3],
-               (unsigned long long)tm[4], (unsigned long long)tm[5]);
-#endif
 }
 
 }  // namespace rsx

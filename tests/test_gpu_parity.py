@@ -122,7 +122,7 @@ def test_middle_size_forecast_and_oversized_buckets(rs, torch, orc, t):
     c.close()
 
 
-WIDE_TYPES = [t for t in util.TYPES if util.TYPES[t][0] >= 8 and util.TYPES[t][2] >= 8]
+WIDE_TYPES = [t for t in util.TYPES if util.TYPES[t][0] >= 8 and util.TYPES[t][2] >= 4]
 
 
 @pytest.mark.parametrize("t", WIDE_TYPES)
@@ -574,7 +574,8 @@ ALT_PATHS = [("OPT_TILE_SCHEDULE", 1, "ticketed tiles instead of the static roll
              ("OPT_MID_SORT", 2, "middle sizes always split by the top digit (skewed inputs: oversized buckets through memory)"),
              ("OPT_MID_SORT", 3, "middle sizes always by LSD passes, top digit counted for the forecast"),
              ("OPT_WIDE_SORT", 2, "wide keys always by the 16-bit bucket hybrid"),
-             ("OPT_WIDE_SORT", 0, "wide keys never by the 16-bit bucket hybrid")]
+             ("OPT_WIDE_SORT", 0, "wide keys never by the 16-bit bucket hybrid"),
+             ("OPT_BUCKET_SKIP", 0, "bucket kernels run every LDS pass (no skipped digits, no mending)")]
 
 
 @pytest.mark.parametrize("opt,value,what", ALT_PATHS)

@@ -5,10 +5,13 @@ import torch, radix_sort_amd as rs
 ctx = rs.default_context(0)
 if len(sys.argv) > 1 and int(sys.argv[1]): ctx.set_option(rs.OPT_MAX_REGIONS, int(sys.argv[1]))
 if os.environ.get("DYN"): ctx.set_option(rs.OPT_TILE_SCHEDULE, 1)
-for key in ("u32", "u64"):
-    d = rs.PRIMITIVES[key]
+if os.environ.get("NOSKIP"): ctx.set_option(rs.OPT_BUCKET_SKIP, 0)
+import bench
+for key in os.environ.get("KEYS", "u32,u64").split(";"):
+    d = bench.digits_for(rs, key)
     out = []
     for lg in (14, 16, 18, 20, 22, 24):
+        if lg > 20 and d.elem_bytes >= 16: continue
         n = 1 << lg
         x = torch.empty(n * d.elem_bytes, dtype=torch.uint8, device="cuda"); tmp = torch.empty_like(x)
         reps = 20
