@@ -54,10 +54,11 @@ WORKLOADS = {
     "u16-256m": ("u16", 28, "uniform", 0.0, "256M u16 uniform keys (2 passes)"),
     "u8-256m": ("u8", 28, "uniform", 0.0, "256M u8 uniform keys (counting path)"),
     "pairs-128m-u64u64": ("(u64,u64)", 27, "uniform", 0.0, "128M (u64,u64) pairs (reference bench type, main.rs:123)"),
+    "u128-128m": ("u128", 27, "uniform", 0.0, "128M u128 uniform keys (16 digits)"),
 }
 HEADLINE = "c3-1b-u64"  # the largest single-GPU configuration in BASELINE.json's configs (configs[2])
 EXTRA_DEFAULT = ["target-1b-u32", "c2-256m-u32", "c4-slice-512m-u32", "zipf-256m-u32", "step16-256m-u32", "zipf-256m-u64", "c5-slice-128m-pairs-zipf",
-                 "c1-1m-u32", "u16-256m"]
+                 "pairs-128m-u64u64", "u128-128m", "c1-1m-u32", "u16-256m"]
 
 
 PATH_NAMES = ["general passes", "one-launch sort", "middle-size bucket split", "one-byte counting", "two-byte counting",
@@ -373,6 +374,9 @@ def main():
                 extra[wl]["steps"] = args.steps
                 extra[wl]["sweep_traffic_bytes_per_launch"] = pmc_traffic(wl)
                 extra[wl]["paths"] = r["paths"]
+                if "bucket_ms_per_launch" in r:  # the hybrid: its three stages per sort
+                    extra[wl]["hybrid_ms"] = {"count16": r.get("count16_ms_per_sort"), "sweeps (2)": 2 * r["sweep_ms_per_launch"],
+                                              "bucket16": r["bucket_ms_per_launch"]}
             except Exception as e:  # noqa: BLE001  (an extra must never kill the headline)
                 extra[wl] = {"error": repr(e)}
         if args.cpu_ladder:

@@ -121,9 +121,11 @@ enum {
                                   0: never; 1 (default): arrays of 2 GiB and more, when the count says every bucket
                                   fits; 2: always (any array of 65536+ such elements, buckets that do not fit go through
                                   memory); 3: as 1 without the size floor (above the middle sizes) */
-    RSX_OPT_BUCKET_SKIP = 13   /* the hybrid's LDS passes: 1 (default) start at the digit that leaves four passes (a 16-bit
+    RSX_OPT_BUCKET_SKIP = 13,  /* the hybrid's LDS passes: 1 (default) start at the digit that leaves four passes (a 16-bit
                                   bucket is, as a rule, told apart by its next 32 bits) and put right the neighbours that
                                   still agree, by the digits skipped; 0: every pass */
+    RSX_OPT_BUCKET_GROUP = 14  /* the hybrid on arrays whose 16-bit buckets are small (8-byte and wider keys): 1 (default)
+                                  a workgroup sorts a group of consecutive buckets as one array; 0: bucket by bucket */
 };
 int rsx_ctx_set_option(rsx_ctx *ctx, int option, uint64_t value);
 enum {

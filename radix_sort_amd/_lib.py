@@ -23,7 +23,7 @@ PROF_HIST, PROF_SCAN, PROF_SWEEP, PROF_OTHER, PROF_KINDS = 0, 1, 2, 3, 4
 GEN_UNIFORM, GEN_ZIPF, GEN_STEP, GEN_SORTED, GEN_REVERSED, GEN_CONSTANT, GEN_GEOMETRIC = 0, 1, 2, 3, 4, 5, 6
 GEN_PAYLOAD_ZERO = 0x100
 (OPT_TILE_SCHEDULE, OPT_RANKING, OPT_STATUS_SCOPE, OPT_XCD_MAJOR, OPT_BYTE_COUNTING, OPT_MAX_REGIONS, OPT_HOT_LANES,
- OPT_VERBOSE, OPT_RANK_CHECK, OPT_SMALL_SORT, OPT_MID_SORT, OPT_WIDE_SORT, OPT_BUCKET_SKIP) = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13
+ OPT_VERBOSE, OPT_RANK_CHECK, OPT_SMALL_SORT, OPT_MID_SORT, OPT_WIDE_SORT, OPT_BUCKET_SKIP, OPT_BUCKET_GROUP) = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14
 INFO_RANK_ATOMIC, INFO_L2_LOCAL, INFO_NUM_CU, INFO_DEVICE, INFO_LAST_PASSES = 1, 2, 3, 4, 5
 SHARD_EXCHANGE_FIRST, SHARD_SORT_FIRST = 0, 1
 

@@ -349,11 +349,12 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
     // once costs ~5 us: nothing beside milliseconds).  A refused try costs its count (one read of the array): the
     // verdict is also written host-visibly, and after a refusal the context goes 15 sorts without trying.
     const uint32_t es = L->elem_bytes;
-    // Where it pays (measured, uniform keys, hybrid / LSD passes): u64 x1.25 at 2^26, x1.6-1.8 from 2^27 on; (u64,u64)
-    // x1.1 at 2^24, x1.9 from 2^26; u128 x1.5 at 2^23, x3.7 from 2^26; (u32,u32) x1.2 from 2^28 (two of four passes in
-    // LDS).  Below those sizes its fixed costs (65536 buckets, ~0.6 ms) lose against the plain passes.
+    // Where it pays (measured, uniform keys, LSD passes / hybrid): keys of 8 and 16 bytes everywhere above the middle
+    // sizes -- u64 2^23 x1.34, 2^26 x1.29, 2^28 x1.9; (u64,u64) 2^22 x1.3, 2^26 x1.9; u128 2^22 x2.4, 2^26 x3.8 (small
+    // buckets are sorted in groups, rsx_bucket16_kernel) --; 4-byte keys in 8-byte and wider elements (two of four passes
+    // in LDS) x1.2 from 2 GiB on, not below.
     const bool wide_type = es >= 8 && D >= 4;
-    const size_t wide_floor = D >= 16 ? ((size_t)128 << 20) : D >= 8 ? (es >= 16 ? ((size_t)256 << 20) : ((size_t)512 << 20)) : ((size_t)2 << 30);
+    const size_t wide_floor = D >= 8 ? 0 : ((size_t)2 << 30);
     const bool wide_size = wide_type && (uint64_t)n > mid_max_for(es);
     bool wide = false;
     if (ctx->wide_mode == 2) {
@@ -671,6 +672,10 @@ int rsx_ctx_set_option(rsx_ctx* ctx, int option, uint64_t value) try {
         case RSX_OPT_BUCKET_SKIP:
             if (value > 1) return fail(ctx, RSX_ERR_ARG, "RSX_OPT_BUCKET_SKIP: 0 or 1");
             ctx->bucket_no_skip = value == 0 ? 1u : 0u;
+            return RSX_OK;
+        case RSX_OPT_BUCKET_GROUP:
+            if (value > 1) return fail(ctx, RSX_ERR_ARG, "RSX_OPT_BUCKET_GROUP: 0 or 1");
+            ctx->bucket_group = (uint32_t)value;
             return RSX_OK;
         case RSX_OPT_MID_SORT:
             if (value > 3) return fail(ctx, RSX_ERR_ARG, "RSX_OPT_MID_SORT: 0 (off), 1 (forecast), 2 (always split) or 3 (always LSD passes)");

@@ -88,6 +88,7 @@ struct rsx_ctx {
     char* wide_buf = nullptr;   // wide-key hybrid: bin totals [65536] u64, bin-block sums [256] u64, bucket starts [65537] u64, verdict u32
     uint32_t wide_mode = 1;     // RSX_OPT_WIDE_SORT: 0 off, 1 auto, 2 always, 3 auto without the size floor
     uint32_t bucket_no_skip = 0;  // RSX_OPT_BUCKET_SKIP == 0
+    uint32_t bucket_group = 1;    // RSX_OPT_BUCKET_GROUP: small buckets of the hybrid are sorted in groups
     uint32_t* ovf16 = nullptr;  // u16 / i16 counting path: 65536 overflow counters, all zero between sorts
     unsigned long long* part_J = nullptr;  // rsx_partition_count_device: one count matrix per sub-range (PART_MAX_SUB x J_BYTES)
     hipStream_t shard_stream = nullptr;

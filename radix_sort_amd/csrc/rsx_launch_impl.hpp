@@ -308,10 +308,12 @@ int launch_mid_split(rsx_ctx* ctx, const void* src, void* dst, size_t n, const r
 // ---- ... then the 256 buckets, each sorted by one workgroup --------------------------------------
 // the bucket kernels start their LDS passes at digit passes - 4 (RSX_OPT_BUCKET_SKIP) and compare neighbours on the key
 // bytes from there up
-inline void set_skip_mask(rsx_ctx* ctx, SmallArgs& a, const rsx_layout* L) {
+inline void set_skip_mask(rsx_ctx* ctx, SmallArgs& a, const rsx_layout* L, uint32_t keep = 4) {
     a.no_skip = ctx->bucket_no_skip;
-    if (a.passes > 4 && !a.no_skip)
-        for (uint32_t byte = L->key_offset + a.passes - 4; byte < L->key_offset + L->key_bytes; ++byte) a.cmp_mask[byte >> 2] |= 0xFFu << (8 * (byte & 3));
+    a.keep = keep;
+    std::memset(a.cmp_mask, 0, sizeof a.cmp_mask);
+    if (a.passes > keep && !a.no_skip)
+        for (uint32_t byte = L->key_offset + a.passes - keep; byte < L->key_offset + L->key_bytes; ++byte) a.cmp_mask[byte >> 2] |= 0xFFu << (8 * (byte & 3));
 }
 
 template <int ES>
@@ -434,7 +436,21 @@ int launch_bucket16(rsx_ctx* ctx, void* data, void* scratch, size_t n, const rsx
             if (per_cu > 4 * RSX_B16_WAVES(WGS) * 64 / WGS) per_cu = 4 * RSX_B16_WAVES(WGS) * 64 / WGS;
             hipLaunchKernelGGL(kern, dim3((uint32_t)(ctx->num_cu * per_cu)), dim3(WGS), lds, st, a, starts, scratch, ctx->gate);
         };
-        if (avg <= (uint64_t)256 * KPT) go(std::integral_constant<int, 256>{});
+        // small buckets: groups of 2^gs consecutive buckets of about 3/4 of what a 512-thread workgroup holds, sorted by
+        // all D digits (keys of at least 8 bytes: five passes and a mend instead of four per bucket)
+        uint32_t gs = 0;
+        if (L->key_bytes >= 8 && ctx->bucket_group)
+            while (gs < 7 && (avg << (gs + 1)) <= (uint64_t)512 * KPT * 3 / 4) ++gs;
+        if (gs >= 2) {
+            a.group_shift = gs;
+            a.passes = L->key_bytes;
+            for (uint32_t d = 0; d < L->key_bytes; ++d) {
+                a.spec[d] = make_spec(L, d);
+                a.spec[d].flip = 0;
+            }
+            set_skip_mask(ctx, a, L, 5);
+            go(std::integral_constant<int, 512>{});
+        } else if (avg <= (uint64_t)256 * KPT) go(std::integral_constant<int, 256>{});
         else if (avg <= (uint64_t)512 * KPT) go(std::integral_constant<int, 512>{});
         else go(std::integral_constant<int, 1024>{});
         RSX_HIP(hipGetLastError());

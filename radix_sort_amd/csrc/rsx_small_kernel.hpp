@@ -33,7 +33,9 @@ struct SmallArgs {
     const uint32_t* top_tot;          // the 256 totals of the top digit (rsx_tilescan_kernel)
     uint32_t cap;                     // elements a 1024-thread workgroup sorts in LDS (a 256-thread one: a quarter)
     uint32_t no_skip;                 // bucket16 kernel: run every pass (1), or start at the digit that leaves four and mend (0)
+    uint32_t keep;                    // ... how many passes that start leaves (4; 5 for groups of buckets)
     uint32_t cmp_mask[8];             // ... the bits of the key from that digit up, per element dword
+    uint32_t group_shift;             // bucket16 kernel: a workgroup takes 2^group_shift consecutive buckets as ONE array
     uint32_t* hint;                   // host-visible report for the host's next forecast: 1 = every bucket of this input fits a
                                       // 256-thread workgroup, 3 = a 1024-thread one, 2 = some bucket fits neither
 };
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(WG) void rsx_bucket_sort_kernel(const SmallArgs a) 
         return;
     }
     // (as in rsx_bucket16_kernel: the passes start at the digit that leaves four, neighbours that still agree are mended)
-    uint32_t skip = (a.passes > 4 && !a.no_skip) ? a.passes - 4 : 0;
+    uint32_t skip = (a.passes > a.keep && !a.no_skip) ? a.passes - a.keep : 0;
     uint32_t* s_flag = reinterpret_cast<uint32_t*>(smem + (size_t)WG * KPT * sizeof(Elem<ES>)) + (WG / WAVE) * RADIX + (WG / WAVE);
     local_sort_skip<ES, KPT, WG>(a, static_cast<const Elem<ES>*>(a.src) + start, static_cast<Elem<ES>*>(a.data) + start, (uint32_t)count, smem,
                                  skip, s_flag);
@@ -471,21 +473,40 @@ __global__ __launch_bounds__(WG, RSX_B16_WAVES(WG)) void rsx_bucket16_kernel(con
     // the passes start at the digit that leaves four (32 bits for at most 2^15 elements), the neighbours that still
     // agree afterwards are put right one run at a time (local_mend), and a workgroup that meets an input where that
     // does not work -- long runs: few distinct values in those 32 bits -- runs all passes from then on.
-    uint32_t skip = (a.passes > 4 && !a.no_skip) ? a.passes - 4 : 0;
+    uint32_t skip = (a.passes > a.keep && !a.no_skip) ? a.passes - a.keep : 0;
     // (Requesting the next bucket ahead of this one's check and store -- its registers are free after the last scatter --
     // would cover a 4.6 us round trip of 31 per bucket on 2^30 u64, but every form of that loop tried spilled 50-370
     // registers and ran slower.)
-    for (uint32_t b = blockIdx.x; b < 65536u; b += gridDim.x) {
-        const uint64_t start = starts[b];
-        const uint64_t count = starts[b + 1] - start;  // (the same for every thread: uniform control flow below)
-        if (count == 0) continue;
-        E* bucket = static_cast<E*>(a.data) + start;
-        if (count > (uint64_t)WG * KPT) {  // an even number of passes: ends where it began
-            big_bucket_sort<ES, KPT, WG>(a, bucket, static_cast<E*>(scratch) + start, (uint32_t)count, smem);
-        } else {
-            local_sort_skip<ES, KPT, WG>(a, bucket, bucket, (uint32_t)count, smem, skip, s_flag);
+    // Small buckets (2^24 u64 keys: 256 each) cost a workgroup ~8 us apiece whatever they hold.  The host then sets
+    // group_shift: 2^group_shift consecutive buckets -- a contiguous range of the final order -- are sorted as ONE array,
+    // by ALL the key's digits (a.passes = D; the passes start at the digit that leaves five: the top 16 bits vary little
+    // inside a group).  A group that does not fit after all is done bucket by bucket, every pass.
+    const uint32_t gs = a.group_shift;
+    for (uint32_t g = blockIdx.x; g < (65536u >> gs); g += gridDim.x) {
+        const uint32_t b0 = g << gs;
+        const uint64_t gstart = starts[b0];
+        const uint64_t gcount = starts[b0 + (1u << gs)] - gstart;  // (the same for every thread: uniform control flow below)
+        if (gcount == 0) continue;
+        const bool whole = gs == 0 || gcount <= (uint64_t)WG * KPT;
+        const uint32_t nsub = whole ? 1u : 1u << gs;
+        for (uint32_t sub = 0; sub < nsub; ++sub) {  // (one call site each for the LDS sort and the sort through memory)
+            uint64_t start = gstart, count = gcount;
+            if (!whole) {
+                start = starts[b0 + sub];
+                count = starts[b0 + sub + 1] - start;
+            }
+            if (count != 0) {
+                E* bucket = static_cast<E*>(a.data) + start;
+                if (count <= (uint64_t)WG * KPT) {
+                    uint32_t sk = whole ? skip : 0u;
+                    local_sort_skip<ES, KPT, WG>(a, bucket, bucket, (uint32_t)count, smem, sk, s_flag);
+                    if (whole) skip = sk;
+                } else {  // an even number of passes: ends where it began
+                    big_bucket_sort<ES, KPT, WG>(a, bucket, static_cast<E*>(scratch) + start, (uint32_t)count, smem);
+                }
+            }
+            __syncthreads();  // smem belongs to the next bucket
         }
-        __syncthreads();  // smem belongs to the next bucket
     }
 }
 

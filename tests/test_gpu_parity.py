@@ -135,15 +135,16 @@ def test_wide_key_hybrid_forced(rs, torch, orc, t):
     c = rs.Context(torch.cuda.current_device())
     c.set_option(rs.OPT_WIDE_SORT, 2)
     rng = np.random.default_rng(31 + d.elem_bytes)
-    for skip in (1, 0):  # LDS passes from the digit that leaves four + mending of the runs that still agree / every pass
+    for skip, group in ((1, 1), (0, 1), (1, 0)):  # skipped digits + mending / every pass; groups of small buckets / one by one
         c.set_option(rs.OPT_BUCKET_SKIP, skip)
+        c.set_option(rs.OPT_BUCKET_GROUP, group)
         for i, dist in enumerate(util.DISTS):
             n = int(rng.integers(70000, 400000))
             raw = util.make_input(t, n, dist, seed=300 + i)
             x = torch.from_numpy(raw.copy()).cuda()
             rs.radix_sort(x, digits=d, ctx=c)
             c.check()
-            assert np.array_equal(x.cpu().numpy(), orc.sort_parallel(raw, lay, 8)), (t, n, dist, skip)
+            assert np.array_equal(x.cpu().numpy(), orc.sort_parallel(raw, lay, 8)), (t, n, dist, skip, group)
     c.close()
 
 
@@ -575,7 +576,8 @@ ALT_PATHS = [("OPT_TILE_SCHEDULE", 1, "ticketed tiles instead of the static roll
              ("OPT_MID_SORT", 3, "middle sizes always by LSD passes, top digit counted for the forecast"),
              ("OPT_WIDE_SORT", 2, "wide keys always by the 16-bit bucket hybrid"),
              ("OPT_WIDE_SORT", 0, "wide keys never by the 16-bit bucket hybrid"),
-             ("OPT_BUCKET_SKIP", 0, "bucket kernels run every LDS pass (no skipped digits, no mending)")]
+             ("OPT_BUCKET_SKIP", 0, "bucket kernels run every LDS pass (no skipped digits, no mending)"),
+             ("OPT_BUCKET_GROUP", 0, "the hybrid sorts small 16-bit buckets one by one (no groups)")]
 
 
 @pytest.mark.parametrize("opt,value,what", ALT_PATHS)
