@@ -88,6 +88,7 @@ def run_single(rs, torch, ctx, wl, steps, warmup, seed0=0x5EED0000, profile=True
     bufs = [torch.empty(nbytes, dtype=torch.uint8, device="cuda") for _ in range(pool)]
     tmp = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
     ctx.reserve(n, d)
+    ctx.set_option(rs.OPT_WIDE_SORT, 1)  # (the default; setting it makes the context forget what an earlier workload's keys looked like)
     stream = torch.cuda.current_stream().cuda_stream
 
     def fill(i, b):

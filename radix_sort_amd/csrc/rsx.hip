@@ -361,14 +361,21 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
         wide = wide_type && n >= 65536;
     } else if (((ctx->wide_mode == 1 && n * (size_t)es >= wide_floor) || ctx->wide_mode == 3) && wide_size &&
                (uint64_t)n / 65536u < (uint64_t)bucket_cap_for(es)) {  // (the real test is the device's, on the actual counts)
-        volatile uint32_t* hint = reinterpret_cast<volatile uint32_t*>(ctx->host_err) + 9;  // the last try's verdict: 1 taken, 2 refused
-        if (ctx->wide_skip > 0) {
+        // the last try's verdict (1 taken, 2 refused) counts for arrays like the one it was given on: same layout, n
+        // within a factor of two (the multi-GPU drivers sort value ranges of slightly different lengths)
+        volatile uint32_t* hint = reinterpret_cast<volatile uint32_t*>(ctx->host_err) + 9;
+        const uint64_t sig = 1ull | (uint64_t)(63 - __builtin_clzll((unsigned long long)n)) << 8 | (uint64_t)es << 16 | (uint64_t)L->key_offset << 24 |
+                             (uint64_t)D << 32 | (uint64_t)L->key_kind << 40;
+        if (ctx->wide_skip > 0 && sig == ctx->wide_refused_sig) {
             --ctx->wide_skip;
-        } else if (*hint == 2u) {
+        } else if (*hint == 2u && sig == ctx->wide_tried_sig) {
             *hint = 0;
             ctx->wide_skip = 15;
+            ctx->wide_refused_sig = sig;
         } else {
+            if (*hint == 2u) *hint = 0;
             wide = true;
+            ctx->wide_tried_sig = sig;
         }
     }
     if (wide && (ctx->ovf16 == nullptr || ctx->wide_buf == nullptr) && capturing(st)) wide = false;

@@ -87,6 +87,7 @@ struct rsx_ctx {
     uint32_t wide_skip = 0;     // sorts to go without trying the wide-key hybrid (the last try was refused on the device)
     char* wide_buf = nullptr;   // wide-key hybrid: bin totals [65536] u64, bin-block sums [256] u64, bucket starts [65537] u64, verdict u32
     uint32_t wide_mode = 1;     // RSX_OPT_WIDE_SORT: 0 off, 1 auto, 2 always, 3 auto without the size floor
+    uint64_t wide_tried_sig = 0, wide_refused_sig = 0;  // (layout, n) of the last hybrid try / of the last refusal
     uint32_t bucket_no_skip = 0;  // RSX_OPT_BUCKET_SKIP == 0
     uint32_t bucket_group = 1;    // RSX_OPT_BUCKET_GROUP: small buckets of the hybrid are sorted in groups
     uint32_t* ovf16 = nullptr;  // u16 / i16 counting path: 65536 overflow counters, all zero between sorts
