@@ -171,16 +171,20 @@ int mid_split_dispatch(rsx_ctx* ctx, const void* src, void* dst, size_t n, const
 int bucket_dispatch(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L, hipStream_t st) {
     RSX_DISPATCH_ES(L->elem_bytes, launch_bucket_sort, ctx, src, dst, g, L, st)
 }
-int count16top_dispatch(rsx_ctx* ctx, const void* src, size_t n, const rsx_layout* L, uint32_t* P, uint32_t parts, uint32_t region_shift,
-                        uint32_t k, hipStream_t st) {
-    RSX_DISPATCH_ES(L->elem_bytes, launch_count16top, ctx, src, n, L, P, parts, region_shift, k, st)
+int wideplan_dispatch(rsx_ctx* ctx, const void* src, size_t n, const rsx_layout* L, WidePlan* plan, hipStream_t st) {
+    RSX_DISPATCH_ES(L->elem_bytes, launch_wideplan, ctx, src, n, L, plan, st)
+}
+int count16top_dispatch(rsx_ctx* ctx, const void* src, size_t n, const rsx_layout* L, WidePlan* plan, uint32_t* P, uint32_t parts,
+                        uint32_t region_shift, uint32_t k, hipStream_t st) {
+    RSX_DISPATCH_ES(L->elem_bytes, launch_count16top, ctx, src, n, L, plan, P, parts, region_shift, k, st)
 }
 int marginal16_dispatch(rsx_ctx* ctx, const uint32_t* P, uint32_t parts, uint32_t k, const RegionGeom& g, const rsx_layout* L,
                         unsigned long long* J, unsigned long long* jclear, hipStream_t st) {
     RSX_DISPATCH_ES(L->elem_bytes, launch_marginal16, ctx, P, parts, k, g, J, jclear, st)
 }
-int bucket16_dispatch(rsx_ctx* ctx, void* data, void* scratch, size_t n, const rsx_layout* L, const uint64_t* starts, hipStream_t st) {
-    RSX_DISPATCH_ES(L->elem_bytes, launch_bucket16, ctx, data, scratch, n, L, starts, st)
+int bucket16_dispatch(rsx_ctx* ctx, void* data, void* scratch, size_t n, const rsx_layout* L, const uint64_t* starts, const WidePlan* plan,
+                      hipStream_t st) {
+    RSX_DISPATCH_ES(L->elem_bytes, launch_bucket16, ctx, data, scratch, n, L, starts, plan, st)
 }
 int small_dispatch(rsx_ctx* ctx, void* data, size_t n, const rsx_layout* L, hipStream_t st) {
     RSX_DISPATCH_ES(L->elem_bytes, launch_small_sort, ctx, data, n, L, st)
@@ -384,11 +388,12 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
             RSX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->ovf16), 65536 * sizeof(uint32_t)));
             RSX_HIP(hipMemsetAsync(ctx->ovf16, 0, 65536 * sizeof(uint32_t), st));
         }
-        if (!ctx->wide_buf) RSX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->wide_buf), (65536 + 256 + 65537 + 1) * sizeof(uint64_t)));
+        if (!ctx->wide_buf) RSX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->wide_buf), WIDE_PLAN_OFFSET + sizeof(WidePlan)));
         uint64_t* tot = reinterpret_cast<uint64_t*>(ctx->wide_buf);
         uint64_t* BT = tot + 65536;
         uint64_t* starts = BT + 256;
-        uint32_t* verdict = reinterpret_cast<uint32_t*>(starts + 65537);
+        WidePlan* plan = reinterpret_cast<WidePlan*>(reinterpret_cast<char*>(ctx->wide_buf) + WIDE_PLAN_OFFSET);
+        const uint32_t* verdict = &plan->verdict;
         const RegionGeom geom = make_geom(ctx, n, es);
         // the count's workgroups: k per region of the sweeps' geometry where the scratch array holds their counters
         // (128 KiB each) -- then the first sweep's count matrix is a marginal of those counters -- and no counter can
@@ -399,14 +404,16 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
         static_assert(bucket_cap(8) < 0x8000u, "a bucket that fits LDS must not overflow a 16-bit counter");
         uint32_t k = ctx->wide_mode == 2 ? 0u : (uint32_t)(parts / geom.num_regions);
         if (k > 0) parts = (size_t)k * geom.num_regions;
-        rc = count16top_dispatch(ctx, d_data, n, L, static_cast<uint32_t*>(d_tmp), (uint32_t)parts, geom.region_shift, k, st);  // partial counts in d_tmp
+        rc = wideplan_dispatch(ctx, d_data, n, L, plan, st);
+        if (rc) return rc;
+        rc = count16top_dispatch(ctx, d_data, n, L, plan, static_cast<uint32_t*>(d_tmp), (uint32_t)parts, geom.region_shift, k, st);  // partial counts in d_tmp
         if (rc) return rc;
         {
             LaunchTimer lt(ctx, RSX_PROF_SCAN, st);
             hipLaunchKernelGGL(rsx_total16_kernel, dim3(256), dim3(256), 0, st, static_cast<const uint32_t*>(d_tmp), (uint32_t)parts, ctx->ovf16, tot, BT);
             RSX_HIP(hipGetLastError());
             hipLaunchKernelGGL(rsx_scan16_kernel, dim3(1), dim3(1024), 0, st, tot, starts,
-                               ctx->wide_mode == 2 ? ~0ull : (uint64_t)bucket_cap_for(es), verdict, ctx->host_err_dev + 9);
+                               ctx->wide_mode == 2 ? ~0ull : (uint64_t)bucket_cap_for(es), plan, ctx->host_err_dev + 9);
             RSX_HIP(hipGetLastError());
         }
         rc = begin_control(ctx, st, geom, false);
@@ -415,19 +422,27 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
         ctx->cb_last = ctx->cb;
         // sequence 1 (verdict 1): LSD passes on digits D-2 and D-1, then every 16-bit bucket in LDS
         ctx->gate = Gate{verdict, 1u};
-        if (k > 0) rc = marginal16_dispatch(ctx, static_cast<const uint32_t*>(d_tmp), (uint32_t)parts, k, geom, L, J_of(ctx, 0), J_of(ctx, 1), st);
-        else rc = hist_dispatch(ctx, d_data, geom, L, D - 2, J_of(ctx, 0), J_of(ctx, 1), true, st);
-        if (rc == RSX_OK) {
+        if (k > 0) {
+            rc = marginal16_dispatch(ctx, static_cast<const uint32_t*>(d_tmp), (uint32_t)parts, k, geom, L, J_of(ctx, 0), J_of(ctx, 1), st);
+        } else {  // (forced mode: counters may have overflowed; a count kernel of its own, its digit from the plan)
+            ctx->spec_dev = &plan->specs[0];
+            rc = hist_dispatch(ctx, d_data, geom, L, D - 2, J_of(ctx, 0), J_of(ctx, 1), true, st);
+            ctx->spec_dev = nullptr;
+        }
+        if (rc == RSX_OK) {  // (the two digits of the window come from the plan, not from the digit index given here)
             ctx->pass_index = 0;
             ctx->pass_last = false;
+            ctx->spec_dev = &plan->specs[0];
             rc = sweep_dispatch(ctx, d_data, d_tmp, geom, L, D - 2, J_of(ctx, 0), J_of(ctx, 1), nullptr, 1, st);  // keys mapped on load
         }
         if (rc == RSX_OK) {
             ctx->pass_index = 1;
             ctx->pass_last = true;
+            ctx->spec_dev = &plan->specs[1];
             rc = sweep_dispatch(ctx, d_tmp, d_data, geom, L, D - 1, J_of(ctx, 1), nullptr, nullptr, 0, st);  // ... and stay mapped
         }
-        if (rc == RSX_OK) rc = bucket16_dispatch(ctx, d_data, d_tmp, n, L, starts, st);
+        ctx->spec_dev = nullptr;
+        if (rc == RSX_OK) rc = bucket16_dispatch(ctx, d_data, d_tmp, n, L, starts, plan, st);
         // sequence 2 (verdict 2): the D LSD passes
         if (rc == RSX_OK) {
             ctx->gate = Gate{verdict, 2u};
@@ -717,7 +732,7 @@ int rsx_ctx_get_info(rsx_ctx* ctx, int what, uint64_t* out) try {
             uint32_t path = ctx->last_path, passes = ctx->last_sort_passes;
             if (path == 5 && ctx->wide_buf) {  // both sequences were enqueued: the device's verdict says which one ran
                 uint32_t verdict = 0;
-                RSX_HIP(hipMemcpy(&verdict, reinterpret_cast<uint64_t*>(ctx->wide_buf) + 65536 + 256 + 65537, sizeof verdict, hipMemcpyDeviceToHost));
+                RSX_HIP(hipMemcpy(&verdict, reinterpret_cast<char*>(ctx->wide_buf) + WIDE_PLAN_OFFSET, sizeof verdict, hipMemcpyDeviceToHost));
                 if (verdict == 1u) passes = 2;
                 else path = 0;
             }

@@ -108,6 +108,26 @@ __device__ __forceinline__ uint32_t elem_digit(const Elem<ES>& e, const DigitSpe
     return d;
 }
 
+// A digit at ANY bit offset of the element, possibly across two dwords (the wide-key hybrid places its window below the
+// highest bit in which the keys differ, wherever that is): the plain digit of a MAPPED key.  One funnel shift more than
+// elem_digit; used by the hybrid's kernels only (STR instantiation of the sweep).
+template <int ES>
+__device__ __forceinline__ uint32_t elem_digit_any(const Elem<ES>& e, const DigitSpec& s) {
+    if constexpr (ES < 8) {
+        return elem_digit<ES, false>(e, s);
+    } else {
+        const uint32_t lo = elem_word<ES>(e, s.word);
+        if (s.shift <= 24u) return (lo >> s.shift) & 0xFFu;  // (wave-uniform: the digit ends inside this dword)
+        const uint32_t hi = elem_word<ES>(e, s.word + 1u);
+        return (uint32_t)((((uint64_t)hi << 32) | lo) >> s.shift) & 0xFFu;
+    }
+}
+template <int ES, bool STR>
+__device__ __forceinline__ uint32_t sweep_digit(const Elem<ES>& e, const DigitSpec& s) {
+    if constexpr (STR) return elem_digit_any<ES>(e, s);
+    else return elem_digit<ES, false>(e, s);
+}
+
 // Signed and float keys are sorted in their order-preserving unsigned form (radix_digits.rs:
 // x ^ MIN, :55-101; b ^ ((b >> 31) | MIN), :103-124).  Instead of mapping every digit of every
 // pass, the FIRST pass of a sort maps the key once while the elements sit in registers and
@@ -272,6 +292,25 @@ __device__ __forceinline__ bool gate_open(const Gate& g) {
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(g.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == g.value;
 }
 
+// The plan of a wide-key hybrid sort, made on the device from a sample of the array (rsx_wideplan_kernel) and read by
+// every kernel of the hybrid: WHICH 16 bits of the mapped key the array is partitioned by -- the two 8-bit digits below
+// the highest bit in which the sampled keys differ (keys of a narrow range, value ranges of a multi-GPU sort: the bits
+// above are the same for all, which rsx_count16top_kernel verifies on every element) -- and which byte digits are left
+// for the LDS passes.
+struct WidePlan {
+    uint32_t verdict;     // rsx_scan16_kernel: 1 the hybrid runs, 2 the LSD passes (the Gate word of both sequences)
+    uint32_t violation;   // some element differs from the sample above the window (or the sample cannot place one): refuse
+    uint32_t pass_end;    // single buckets: the LDS passes are byte digits [pass_end - keep or 0, pass_end) of the key
+    uint32_t keep;
+    uint32_t group_end;   // groups of buckets: digits [group_end - group_keep or 0, group_end)
+    uint32_t group_keep;
+    uint32_t window_top;  // key bit index of the window's top bit (diagnostic)
+    uint32_t pad;
+    DigitSpec specs[3];   // [0] low, [1] high digit of the window (plain digits of the MAPPED key); [2] filler (sweeps read pairs)
+    uint32_t ref[8];      // the mapped first element
+    uint32_t himask[8];   // key bits above the window, per element dword
+};
+
 // --------------------------------------------------------------- histogram --
 #ifndef RSX_HIST_NT
 // The count kernel reads its input with the streaming hint: it arrives behind a sort whose output still sits,
@@ -315,8 +354,10 @@ __global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restric
                                                        unsigned long long* __restrict__ jclear, uint32_t j32,
                                                        uint4* __restrict__ zero16, uint64_t zero16_n,
                                                        CleanList clean, Gate gate,
-                                                       DigitSpec spec2 = DigitSpec{}, unsigned long long* __restrict__ J2 = nullptr) {
+                                                       DigitSpec spec2 = DigitSpec{}, unsigned long long* __restrict__ J2 = nullptr,
+                                                       const DigitSpec* __restrict__ spec_dev = nullptr) {
     if (!gate_open(gate)) return;
+    if (spec_dev != nullptr) spec = *spec_dev;  // the hybrid's forced mode: the digit comes from the device's plan
     // One-byte elements make 16 LDS atomics per 16-byte load, and random bins collide on the 32 banks (72 % of this
     // kernel's LDS cycles were bank conflicts: profiles/r03_u8-256m_pmc.txt): their histogram is kept in 32 copies,
     // copy l in bank l -- lane l of either half-wave adds to lh[bin * 32 + l % 32], so an instruction never has two
@@ -333,7 +374,16 @@ __global__ __launch_bounds__(512) void rsx_hist_kernel(const Elem<ES>* __restric
     uint64_t end = begin + (1ull << g.region_shift);
     if (end > g.n) end = g.n;
     auto count = [&](const Elem<ES>& e) {
-        const uint32_t d = elem_digit<ES, FLT>(e, spec);
+        uint32_t d;
+        if (spec_dev != nullptr) {  // (the hybrid's forced mode: a window digit at any bit offset, of the RAW key)
+            d = elem_digit_any<ES>(e, spec);
+            if constexpr (FLT) {
+                const uint32_t neg = (uint32_t)((int32_t)(elem_word<ES>(e, spec.top_word) << (31u - spec.top_shift)) >> 31) & spec.fsign;
+                d ^= (neg & 0xFFu) | (~neg & spec.flip);
+            }
+        } else {
+            d = elem_digit<ES, FLT>(e, spec);
+        }
         if constexpr (BANKED) {
             atomicAdd(&lh[d * 32u + (tid & 31u)], 1u);
             return;
@@ -453,6 +503,7 @@ struct SweepArgs {
     uint32_t* error;              // host-visible (pinned) word: set non-zero if a bounded spin gave up
     DigitSpec spec;               // this pass's digit
     DigitSpec next;               // next pass's digit (when jnext != null)
+    const DigitSpec* spec_dev;    // non-null: both digits are read from device memory instead (WidePlan::specs)
     KeyXform xf;                  // signed/float key map applied on load (XF & 1) / undone on store (XF & 2)
     uint32_t opts;                // alternative paths, all bit-exact: SWEEP_OPT_*
     // middle-size path (MID instantiation: the sort's first sweep).  The host has decided, from what the previous
@@ -637,7 +688,7 @@ __device__ __forceinline__ void load_tile(Elem<ES> (&e)[KPT], const Elem<ES>* __
     }
 }
 
-template <int ES, int KPT, int WG, typename S, int XF, bool NEXT, bool MID = false>
+template <int ES, int KPT, int WG, typename S, int XF, bool NEXT, bool MID = false, bool STR = false>
 // VGPR budget: 4-byte (and narrower) keys carry 16 elements per thread and need ~104 VGPRs; capping
 // them at 80 (3 workgroups/CU) spills, and the spills cost more than the third workgroup buys
 // (measured: 0.82 -> 0.68 ms per 256M-key pass at 2 workgroups/CU without spills).
@@ -787,6 +838,11 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
     };
     // MID: which digit this launch partitions by, and from which count matrix, is decided below
     DigitSpec spec = a.spec;
+    DigitSpec next = a.next;
+    if (a.spec_dev != nullptr) {  // (uniform: scalar loads)
+        spec = a.spec_dev[0];
+        next = a.spec_dev[1];
+    }
     const unsigned long long* Jsel = a.J;
     bool msd = false;
     auto region_cursors = [&](uint32_t r) {  // r is wave-uniform
@@ -1043,7 +1099,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                 for (int r = 0; r < RG; ++r) {
                     const int j = j0 + r;
                     if (j >= JE) continue;
-                    uint32_t d = elem_digit<ES, false>(e[j], spec);
+                    uint32_t d = sweep_digit<ES, STR>(e[j], spec);
                     if constexpr (!FULL) {
                         if (seg + j * WAVE >= valid) d = 255u;
                     }
@@ -1116,7 +1172,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                 for (int r = 0; r < RG; ++r) {
                     const int j = j0 + r;
                     if (j >= KPT) continue;
-                    uint32_t d = elem_digit<ES, false>(e[j], spec);
+                    uint32_t d = sweep_digit<ES, STR>(e[j], spec);
                     if constexpr (!FULL) {
                         if (seg + j * WAVE >= valid) d = 255u;
                     }
@@ -1279,7 +1335,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
         forget<ES, KPT>(e);
 #pragma unroll
         for (int j = 0; j < KPT; ++j) {
-            const uint32_t d = (!full && seg + j * WAVE >= valid) ? 255u : elem_digit<ES, false>(e[j], spec);
+            const uint32_t d = (!full && seg + j * WAVE >= valid) ? 255u : sweep_digit<ES, STR>(e[j], spec);
             // bank swizzle (RSX_LDS_SWIZZLE): slot p lives at p ^ ((p >> 5) & 31).  Digit runs that start
             // a multiple of 32 slots apart -- every pass over already sorted input, key = index -- would
             // otherwise put all 64 lanes of a wave on one bank
@@ -1370,7 +1426,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                     r = __builtin_amdgcn_alignbit((uint32_t)(idx >> 32), (uint32_t)idx, a.g.region_shift);
                 else
                     r = (uint32_t)(idx >> a.g.region_shift);
-                return (r << 8) | elem_digit<ES, false>(x, a.next);
+                return (r << 8) | sweep_digit<ES, STR>(x, next);
             };
             if (full) {
                 auto write_full = [&](auto crowd, uint32_t hot_nd) __attribute__((always_inline)) {  // duplicated: plain LDS atomics / skew-proof counting
@@ -1390,7 +1446,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                         E x;
                         if (i < PREREAD && preread) x = e[i];
                         else x = s_elems[slot_of(i)];
-                        const uint64_t idx = s_base[elem_digit<ES, false>(x, spec)] + p;
+                        const uint64_t idx = s_base[sweep_digit<ES, STR>(x, spec)] + p;
                         if constexpr ((XF & 2) != 0) {  // last pass: back to the caller's representation
                             E y = x;
                             key_map<ES, true>(y, a.xf);
@@ -1432,7 +1488,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                 bool crowded_next = false;
                 uint32_t hot_nd = 0;
                 if (do_next) {
-                    const uint32_t nd = elem_digit<ES, false>(s_elems[sw0], a.next);
+                    const uint32_t nd = sweep_digit<ES, STR>(s_elems[sw0], next);
                     hot_nd = (uint32_t)__builtin_amdgcn_readfirstlane((int)nd);
                     crowded_next = __popcll(__ballot(nd == hot_nd)) >= 16;
                 }
@@ -1444,7 +1500,7 @@ __attribute__((amdgpu_num_sgpr(RSX_NUM_SGPR))) void rsx_sweep_kernel(const Sweep
                     const uint32_t p = i * WG + tid;
                     if (p < valid) {
                         const E x = s_elems[slot_of(i)];
-                        const uint64_t idx = s_base[elem_digit<ES, false>(x, spec)] + p;
+                        const uint64_t idx = s_base[sweep_digit<ES, STR>(x, spec)] + p;
                         if constexpr ((XF & 2) != 0) {
                             E y = x;
                             key_map<ES, true>(y, a.xf);

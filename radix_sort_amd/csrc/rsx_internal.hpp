@@ -87,6 +87,7 @@ struct rsx_ctx {
     uint32_t wide_skip = 0;     // sorts to go without trying the wide-key hybrid (the last try was refused on the device)
     char* wide_buf = nullptr;   // wide-key hybrid: bin totals [65536] u64, bin-block sums [256] u64, bucket starts [65537] u64, verdict u32
     uint32_t wide_mode = 1;     // RSX_OPT_WIDE_SORT: 0 off, 1 auto, 2 always, 3 auto without the size floor
+    const rsx::DigitSpec* spec_dev = nullptr;  // the hybrid's sweeps read their digits from the device's plan (WidePlan::specs)
     uint64_t wide_tried_sig = 0, wide_refused_sig = 0;  // (layout, n) of the last hybrid try / of the last refusal
     uint32_t bucket_no_skip = 0;  // RSX_OPT_BUCKET_SKIP == 0
     uint32_t bucket_group = 1;    // RSX_OPT_BUCKET_GROUP: small buckets of the hybrid are sorted in groups
@@ -216,6 +217,8 @@ struct LaunchTimer {
 // rsx_bucket_sort_kernel: 1024 threads x BKPT elements in registers, the bucket in LDS (<= 112 KiB, 8-byte elements
 // 136 KiB) beside 16 KiB of wave counters
 constexpr int bucket_kpt_for(int es) { return es <= 4 ? 28 : es == 8 ? 17 : es == 12 ? 9 : es == 16 ? 7 : es == 24 ? 4 : 3; }
+// the hybrid's buffer (ctx->wide_buf): bucket totals [65536], block totals [256], starts [65537] (u64), then its WidePlan
+constexpr size_t WIDE_PLAN_OFFSET = (65536 + 256 + 65537 + 1) * sizeof(uint64_t);
 constexpr uint32_t bucket_cap(int es) { return 1024u * (uint32_t)bucket_kpt_for(es); }
 // Largest array taken by the middle-size path: the average bucket is 4/7 of the capacity, so uniform top digits
 // pass with a wide margin (2^22 4-byte, 2^20 16-byte elements); skewed ones fall back to LSD passes.  8-byte elements
@@ -317,13 +320,16 @@ int launch_mid_split(rsx_ctx* ctx, const void* src, void* dst, size_t n, const r
 // wide keys, large arrays: the top 16 bits of the mapped key counted per workgroup (P[parts][32768]); the 65536
 // buckets (starts[65537]) sorted by the lower digits in LDS, in place
 template <int ES>
-int launch_count16top(rsx_ctx* ctx, const void* src, size_t n, const rsx_layout* L, uint32_t* P, uint32_t parts, uint32_t region_shift,
-                      uint32_t k, hipStream_t st);
+int launch_wideplan(rsx_ctx* ctx, const void* src, size_t n, const rsx_layout* L, WidePlan* plan, hipStream_t st);
+template <int ES>
+int launch_count16top(rsx_ctx* ctx, const void* src, size_t n, const rsx_layout* L, WidePlan* plan, uint32_t* P, uint32_t parts,
+                      uint32_t region_shift, uint32_t k, hipStream_t st);
 template <int ES>
 int launch_marginal16(rsx_ctx* ctx, const uint32_t* P, uint32_t parts, uint32_t k, const RegionGeom& g, unsigned long long* J,
                       unsigned long long* jclear, hipStream_t st);
 template <int ES>
-int launch_bucket16(rsx_ctx* ctx, void* data, void* scratch, size_t n, const rsx_layout* L, const uint64_t* starts, hipStream_t st);
+int launch_bucket16(rsx_ctx* ctx, void* data, void* scratch, size_t n, const rsx_layout* L, const uint64_t* starts, const WidePlan* plan,
+                    hipStream_t st);
 // second half of a middle-size sort: the 256 top-digit buckets of `src` sorted by the lower digits into `dst`
 template <int ES>
 int launch_bucket_sort(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L, hipStream_t st);

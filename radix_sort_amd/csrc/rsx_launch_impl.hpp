@@ -26,7 +26,7 @@ int launch_hist_t(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_
     LaunchTimer lt(ctx, RSX_PROF_HIST, st);
     hipLaunchKernelGGL((rsx_hist_kernel<ES, FLT>), dim3((uint32_t)(bpr * g.num_regions)), dim3(512), 0, st,
                        static_cast<const Elem<ES>*>(src), g, make_spec(L, digit), (uint32_t)bpr, J, jclear, status32(g) ? 1u : 0u,
-                       static_cast<uint4*>(ctx->status), zero16_n, ctx->clean, ctx->gate);
+                       static_cast<uint4*>(ctx->status), zero16_n, ctx->clean, ctx->gate, DigitSpec{}, nullptr, ctx->spec_dev);
     RSX_HIP(hipGetLastError());
     ctx->clean = CleanList{{nullptr, nullptr, nullptr}, {0, 0, 0}};  // done once per sort
     return RSX_OK;
@@ -34,7 +34,7 @@ int launch_hist_t(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_
 template <int ES>
 int launch_hist(rsx_ctx* ctx, const void* src, const RegionGeom& g, const rsx_layout* L, uint32_t digit,
                 unsigned long long* J, unsigned long long* jclear, bool clear_status, hipStream_t st) {
-    if (L->key_kind == RSX_KEY_FLOAT || (L->key_kind == RSX_KEY_SIGNED && digit + 1 == L->key_bytes))
+    if (L->key_kind == RSX_KEY_FLOAT || (L->key_kind == RSX_KEY_SIGNED && (digit + 1 == L->key_bytes || ctx->spec_dev != nullptr)))
         return launch_hist_t<ES, true>(ctx, src, g, L, digit, J, jclear, clear_status, st);
     return launch_hist_t<ES, false>(ctx, src, g, L, digit, J, jclear, clear_status, st);
 }
@@ -84,7 +84,7 @@ inline KeyXform make_xform(const rsx_layout* L) {
     return x;
 }
 
-template <int ES, typename S, int XF, bool NEXT, bool MID = false>
+template <int ES, typename S, int XF, bool NEXT, bool MID = false, bool STR = false>
 int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L,
                    uint32_t digit, const unsigned long long* J, unsigned long long* jnext, unsigned long long* jzero,
                    hipStream_t st) {
@@ -125,6 +125,7 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
     a.mid_spec = a.spec;
     a.mid_cap = 0;
     a.gate = ctx->gate;
+    a.spec_dev = ctx->spec_dev;
     a.mid_mode = ctx->pass_mid;
     a.mid_hint = ctx->host_err_dev + 8;  // second word group of the host-visible block
     if constexpr (MID) {
@@ -138,7 +139,7 @@ int launch_sweep_t(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g
     a.dbg_cnt = reinterpret_cast<unsigned long long*>(ctx->aux + OFF_DBG);
     const size_t lds = (size_t)TILE * ES + (SWEEP_WG / WAVE) * RADIX * ((RSX_WIDE_CNT && ES <= 4 && KPT >= 16 && SWEEP_WG <= 512) ? sizeof(uint32_t) : sizeof(uint16_t)) +
                        (NEXT ? (size_t)g.num_regions * RADIX * sizeof(uint32_t) : 0) + 128;
-    auto kern = rsx_sweep_kernel<ES, KPT, SWEEP_WG, S, XF, NEXT, MID>;
+    auto kern = rsx_sweep_kernel<ES, KPT, SWEEP_WG, S, XF, NEXT, MID, STR>;
     // resident workgroups per CU for this kernel at this LDS size (the count matrix of the next pass
     // makes the LDS size depend on the number of regions): cached per instantiation and thread
     thread_local size_t occ_lds = ~(size_t)0;
@@ -205,6 +206,13 @@ template <int ES, typename S, int XF>
 int launch_sweep_n(rsx_ctx* ctx, const void* src, void* dst, const RegionGeom& g, const rsx_layout* L,
                    uint32_t digit, const unsigned long long* J, unsigned long long* jnext, unsigned long long* jzero,
                    hipStream_t st) {
+    if (ctx->spec_dev != nullptr) {  // the hybrid's two sweeps: window digits at any bit offset (the STR instantiation)
+        if constexpr (ES >= 8 && (XF & 2) == 0) {
+            if (jnext) return launch_sweep_t<ES, S, XF, true, false, true>(ctx, src, dst, g, L, digit, J, jnext, jzero, st);
+            if constexpr (XF == 0) return launch_sweep_t<ES, S, 0, false, false, true>(ctx, src, dst, g, L, digit, J, nullptr, jzero, st);
+        }
+        return fail(ctx, RSX_ERR_INTERNAL, "launch_sweep: no kernel for this pass of the hybrid");
+    }
     if constexpr ((XF & 2) == 0) {  // a pass that maps the keys back is a last pass: nothing to count for
         if constexpr (sizeof(S) == 4 && ES != 1) {  // the first sweep of a middle-size sort (regions of <= 2^30 elements by far)
             if (jnext && ctx->pass_mid != 0) return launch_sweep_t<ES, S, XF, true, true>(ctx, src, dst, g, L, digit, J, jnext, jzero, st);
@@ -361,24 +369,41 @@ int launch_bucket_sort(rsx_ctx* ctx, const void* src, void* dst, const RegionGeo
 }
 
 // ---- wide keys, large arrays: count of the top 16 bits; the buckets sorted in LDS -------------------
+// the hybrid's plan: which 16 bits of the mapped key the array is partitioned by (rsx_wideplan_kernel, one workgroup)
 template <int ES>
-int launch_count16top(rsx_ctx* ctx, const void* src, size_t n, const rsx_layout* L, uint32_t* P, uint32_t parts, uint32_t region_shift,
-                      uint32_t k, hipStream_t st) {
+int launch_wideplan(rsx_ctx* ctx, const void* src, size_t n, const rsx_layout* L, WidePlan* plan, hipStream_t st) {
+    if constexpr (ES < 4) {
+        return fail(ctx, RSX_ERR_INTERNAL, "launch_wideplan: narrow elements");
+    } else {
+        LaunchTimer lt(ctx, RSX_PROF_SCAN, st);
+        if (L->key_kind != RSX_KEY_UNSIGNED)
+            hipLaunchKernelGGL((rsx_wideplan_kernel<ES, true>), dim3(1), dim3(1024), 0, st, static_cast<const Elem<ES>*>(src), (uint64_t)n, L->key_offset,
+                               L->key_bytes, L->key_kind, make_xform(L), plan);
+        else
+            hipLaunchKernelGGL((rsx_wideplan_kernel<ES, false>), dim3(1), dim3(1024), 0, st, static_cast<const Elem<ES>*>(src), (uint64_t)n, L->key_offset,
+                               L->key_bytes, L->key_kind, make_xform(L), plan);
+        RSX_HIP(hipGetLastError());
+        return RSX_OK;
+    }
+}
+
+template <int ES>
+int launch_count16top(rsx_ctx* ctx, const void* src, size_t n, const rsx_layout* L, WidePlan* plan, uint32_t* P, uint32_t parts,
+                      uint32_t region_shift, uint32_t k, hipStream_t st) {
     if constexpr (ES < 4) {
         return fail(ctx, RSX_ERR_INTERNAL, "launch_count16top: narrow elements");
     } else {
-        const DigitSpec lo = make_spec(L, L->key_bytes - 2), hi = make_spec(L, L->key_bytes - 1);
         LaunchTimer lt(ctx, RSX_PROF_HIST, st);
         if (L->key_kind != RSX_KEY_UNSIGNED) {
             auto kern = rsx_count16top_kernel<ES, true>;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-            hipLaunchKernelGGL(kern, dim3(parts), dim3(1024), 131072, st, static_cast<const Elem<ES>*>(src), (uint64_t)n, lo, hi, P, ctx->ovf16,
-                               region_shift, k);
+            hipLaunchKernelGGL(kern, dim3(parts), dim3(1024), 131072, st, static_cast<const Elem<ES>*>(src), (uint64_t)n, plan, make_xform(L), P,
+                               ctx->ovf16, region_shift, k);
         } else {
             auto kern = rsx_count16top_kernel<ES, false>;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-            hipLaunchKernelGGL(kern, dim3(parts), dim3(1024), 131072, st, static_cast<const Elem<ES>*>(src), (uint64_t)n, lo, hi, P, ctx->ovf16,
-                               region_shift, k);
+            hipLaunchKernelGGL(kern, dim3(parts), dim3(1024), 131072, st, static_cast<const Elem<ES>*>(src), (uint64_t)n, plan, make_xform(L), P,
+                               ctx->ovf16, region_shift, k);
         }
         RSX_HIP(hipGetLastError());
         return RSX_OK;
@@ -401,7 +426,8 @@ int launch_marginal16(rsx_ctx* ctx, const uint32_t* P, uint32_t parts, uint32_t 
 }
 
 template <int ES>
-int launch_bucket16(rsx_ctx* ctx, void* data, void* scratch, size_t n, const rsx_layout* L, const uint64_t* starts, hipStream_t st) {
+int launch_bucket16(rsx_ctx* ctx, void* data, void* scratch, size_t n, const rsx_layout* L, const uint64_t* starts, const WidePlan* plan,
+                    hipStream_t st) {
     if constexpr (ES < 4) {
         return fail(ctx, RSX_ERR_INTERNAL, "launch_bucket16: narrow elements");
     } else {
@@ -411,17 +437,20 @@ int launch_bucket16(rsx_ctx* ctx, void* data, void* scratch, size_t n, const rsx
         std::memset(&a, 0, sizeof a);
         a.src = data;
         a.data = data;
-        a.passes = L->key_bytes - 2;
+        a.passes = L->key_bytes - 2;  // (what the sort THROUGH MEMORY of an oversized bucket runs: an even number, every digit the
+                                      // LDS passes could need; the LDS passes themselves follow the device's plan)
         a.rank_atomic = (ctx->rank_atomic && !(ctx->options & OPT_BALLOT_RANKS)) ? 1u : 0u;
         a.map_load = 0;  // the first sweep mapped the keys
         a.map_store = L->key_kind == RSX_KEY_UNSIGNED ? 0u : 1u;
-        for (uint32_t d = 0; d + 2 < L->key_bytes; ++d) {
+        for (uint32_t d = 0; d < L->key_bytes; ++d) {
             a.spec[d] = make_spec(L, d);
             a.spec[d].flip = 0;
         }
         a.xf = make_xform(L);
         a.cap = bucket_cap(ES);
-        set_skip_mask(ctx, a, L);
+        a.no_skip = ctx->bucket_no_skip;
+        a.key_offset = L->key_offset;
+        a.key_bytes = L->key_bytes;
         LaunchTimer lt(ctx, RSX_PROF_OTHER, st);
         // workgroup size by the AVERAGE bucket (a few buckets above the capacity go through memory): 256, 512 or 1024
         // threads x KPT elements, as many workgroups per CU as their LDS allows (3-4, 2, 1)
@@ -434,7 +463,7 @@ int launch_bucket16(rsx_ctx* ctx, void* data, void* scratch, size_t n, const rsx
             int per_cu = (int)((size_t)163840 / lds);
             if (per_cu < 1) per_cu = 1;
             if (per_cu > 4 * RSX_B16_WAVES(WGS) * 64 / WGS) per_cu = 4 * RSX_B16_WAVES(WGS) * 64 / WGS;
-            hipLaunchKernelGGL(kern, dim3((uint32_t)(ctx->num_cu * per_cu)), dim3(WGS), lds, st, a, starts, scratch, ctx->gate);
+            hipLaunchKernelGGL(kern, dim3((uint32_t)(ctx->num_cu * per_cu)), dim3(WGS), lds, st, a, starts, scratch, plan, ctx->gate);
         };
         // small buckets: groups of 2^gs consecutive buckets of about 3/4 of what a 512-thread workgroup holds, sorted by
         // all D digits (keys of at least 8 bytes: five passes and a mend instead of four per bucket)
@@ -444,11 +473,6 @@ int launch_bucket16(rsx_ctx* ctx, void* data, void* scratch, size_t n, const rsx
         if (gs >= 2) {
             a.group_shift = gs;
             a.passes = L->key_bytes;
-            for (uint32_t d = 0; d < L->key_bytes; ++d) {
-                a.spec[d] = make_spec(L, d);
-                a.spec[d].flip = 0;
-            }
-            set_skip_mask(ctx, a, L, 5);
             go(std::integral_constant<int, 512>{});
         } else if (avg <= (uint64_t)256 * KPT) go(std::integral_constant<int, 256>{});
         else if (avg <= (uint64_t)512 * KPT) go(std::integral_constant<int, 512>{});

@@ -174,20 +174,121 @@ __global__ __launch_bounds__(512) void rsx_tilescatter_kernel(const MidArgs a) {
 // digits D-2 and D-1 (after which every bucket is contiguous and in input order), and rsx_bucket16_kernel: every
 // bucket sorted by its remaining D-2 digits in LDS.  Same bytes as D LSD passes (the stable sort by the whole key).
 //
+// rsx_wideplan_kernel: one workgroup looks at 16384 elements spread over the array (and the last one), finds the highest
+// bit in which their mapped keys differ from the first element's, and places the window: the 16 bits from there down
+// (its digits may lie across two dwords of the element: elem_digit_any).
+template <int ES, bool MAP>
+__global__ __launch_bounds__(1024) void rsx_wideplan_kernel(const Elem<ES>* __restrict__ src, uint64_t n, uint32_t key_offset, uint32_t key_bytes,
+                                                            uint32_t key_kind, KeyXform xf, WidePlan* __restrict__ plan) {
+    constexpr int NW = ES / 4;
+    __shared__ uint32_t s_or[16][NW];
+    const uint32_t tid = threadIdx.x;
+    Elem<ES> first = src[0];
+    if constexpr (MAP) key_map<ES, false>(first, xf);
+    uint32_t acc[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) acc[w] = 0;
+    const uint64_t step = n / 16384u > 0 ? n / 16384u : 1;
+    constexpr int BATCH = ES <= 16 ? 8 : 4;  // loads in flight per thread
+    for (uint32_t k0 = 0; k0 < 16; k0 += BATCH) {
+        Elem<ES> e[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            uint64_t i = ((uint64_t)(k0 + u) * 1024u + tid) * step;
+            if (k0 + u == 15 && tid == 1023) i = n - 1;
+            e[u] = src[i < n ? i : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            if constexpr (MAP) key_map<ES, false>(e[u], xf);
+#pragma unroll
+            for (int w = 0; w < NW; ++w) acc[w] |= e[u].w[w] ^ first.w[w];
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        uint32_t v = acc[w];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o);
+        if ((tid & 63u) == 0u) s_or[tid >> 6][w] = v;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    uint32_t diff[NW];
+    for (int w = 0; w < NW; ++w) {
+        diff[w] = 0;
+        for (int q = 0; q < 16; ++q) diff[w] |= s_or[q][w];
+    }
+    // highest differing KEY bit (key bit i is element bit 8 * key_offset + i)
+    int t = -1;
+    for (int bit = (int)key_bytes * 8 - 1; bit >= 0; --bit) {
+        const uint32_t eb = 8u * key_offset + (uint32_t)bit;
+        if ((diff[eb >> 5] >> (eb & 31u)) & 1u) {
+            t = bit;
+            break;
+        }
+    }
+    uint32_t violation = t < 0 ? 1u : 0u;  // every sampled key the same: nothing to place a window by
+    const int top = t < 15 ? 15 : t;
+    const int last = (int)key_bytes * 8 - 1;
+    const uint32_t lo_bit = 8u * key_offset + (uint32_t)(top - 15), hi_bit = lo_bit + 8u;
+    DigitSpec lo{}, hi{};
+    lo.word = lo_bit >> 5;
+    lo.shift = lo_bit & 31u;
+    hi.word = hi_bit >> 5;
+    hi.shift = hi_bit & 31u;
+    // (for the one reader of RAW keys, the count kernel of the forced mode: where the sign sits and what it flips)
+    const uint32_t sign_bit = 8u * key_offset + (uint32_t)last;
+    lo.top_word = hi.top_word = sign_bit >> 5;
+    lo.top_shift = hi.top_shift = sign_bit & 31u;
+    lo.fsign = hi.fsign = key_kind == 2u ? ~0u : 0u;
+    hi.flip = (key_kind != 0u && top == last) ? 0x80u : 0u;
+    plan->specs[0] = lo;
+    plan->specs[1] = hi;
+    plan->specs[2] = hi;
+    const uint32_t b_lo = (uint32_t)(top - 15);                // key bits below the window: [0, b_lo)
+    const uint32_t pass_end = (b_lo + 7u) / 8u;                // byte digits that hold them
+    plan->pass_end = pass_end;
+    plan->keep = (pass_end * 8u - b_lo) != 0u ? 5u : 4u;       // (its top digit reaches into the window: constant bits there)
+    const uint32_t group_end = ((uint32_t)top + 8u) / 8u;      // groups sort by everything up to the window's top
+    plan->group_end = group_end;
+    plan->group_keep = (group_end * 8u - 1u - (uint32_t)top) != 0u ? 6u : 5u;
+    plan->window_top = (uint32_t)top;
+    plan->violation = violation;
+    for (int w = 0; w < 8; ++w) {
+        plan->ref[w] = w < NW ? first.w[w] : 0u;
+        uint32_t m = 0;
+        for (uint32_t b = 0; b < 32; ++b) {
+            const int keybit = (int)(32u * (uint32_t)w + b) - (int)(8u * key_offset);
+            if (keybit > top && keybit <= last) m |= 1u << b;
+        }
+        plan->himask[w] = m;
+    }
+}
+
 // rsx_count16top_kernel: as rsx_count16_kernel (65536 16-bit LDS counters per workgroup, returned atomics, overflow
-// parked in a global table), over elements of ES bytes whose bin is (digit D-1, digit D-2) of the mapped key.
+// parked in a global table), over elements of ES bytes whose bin is the plan's 16-bit window of the mapped key; every
+// element is also checked against the sample above the window (plan->violation).
 // Workgroup b counts chunk b % k of region b / k (k chunks per region; k == 0: the array cut into gridDim.x flat
 // shares): a workgroup then stays inside ONE region of the sweeps' geometry, and the count matrix of the first sweep
-// (digit D-2 = the low byte of the bin, per region) is a marginal of these counters -- rsx_marginal16_kernel reads
+// (the window's low digit, per region) is a marginal of these counters -- rsx_marginal16_kernel reads
 // them back (32 MiB) instead of a count kernel reading the array again (1.37 ms of 21 on 2^30 u64).
-template <int ES, bool FLT>
-__global__ __launch_bounds__(1024) void rsx_count16top_kernel(const Elem<ES>* __restrict__ src, uint64_t n, DigitSpec lo, DigitSpec hi,
+template <int ES, bool MAP>
+__global__ __launch_bounds__(1024) void rsx_count16top_kernel(const Elem<ES>* __restrict__ src, uint64_t n, WidePlan* __restrict__ plan, KeyXform xf,
                                                               uint32_t* __restrict__ P, uint32_t* __restrict__ ovf, uint32_t region_shift,
                                                               uint32_t k) {
+    constexpr int NW = ES / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
     uint32_t* cnt = reinterpret_cast<uint32_t*>(smem16);  // [32768]
     const uint32_t tid = threadIdx.x;
     for (uint32_t i = tid; i < 32768u / 4u; i += 1024u) reinterpret_cast<uint4*>(cnt)[i] = make_uint4(0, 0, 0, 0);
+    const DigitSpec lo = plan->specs[0], hi = plan->specs[1];  // (uniform: scalar loads)
+    uint32_t ref[NW], himask[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        ref[w] = plan->ref[w];
+        himask[w] = plan->himask[w];
+    }
     __syncthreads();
     uint64_t p0, p1;
     if (k == 0) {
@@ -202,8 +303,12 @@ __global__ __launch_bounds__(1024) void rsx_count16top_kernel(const Elem<ES>* __
         if (p1 > r0 + rl) p1 = r0 + rl;
     }
     if (p1 > n) p1 = n;
-    auto count = [&](const Elem<ES>& e) {
-        const uint32_t bin = (elem_digit<ES, FLT>(e, hi) << 8) | elem_digit<ES, FLT>(e, lo);
+    uint32_t stray = 0;
+    auto count = [&](Elem<ES> e) {
+        if constexpr (MAP) key_map<ES, false>(e, xf);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) stray |= (e.w[w] ^ ref[w]) & himask[w];
+        const uint32_t bin = (elem_digit_any<ES>(e, hi) << 8) | elem_digit_any<ES>(e, lo);
         const uint32_t sh = (bin & 1u) * 16u;
         const uint32_t old = atomicAdd(&cnt[bin >> 1], 1u << sh);
         if (((old >> sh) & 0xFFFFu) == 0x7FFFu) {  // my add made it 0x8000: park that half in the overflow table
@@ -221,7 +326,7 @@ __global__ __launch_bounds__(1024) void rsx_count16top_kernel(const Elem<ES>* __
         for (int u = 0; u < UNR; ++u) count(e[u]);
     }
     for (; i < p1; i += 1024u) count(src[i]);
-    __syncthreads();
+    if (__syncthreads_or(stray != 0 ? 1 : 0) && tid == 0) __hip_atomic_store(&plan->violation, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint4* out = reinterpret_cast<uint4*>(P + (size_t)blockIdx.x * 32768u);
     for (uint32_t i4 = tid; i4 < 32768u / 4u; i4 += 1024u) out[i4] = reinterpret_cast<const uint4*>(cnt)[i4];
 }

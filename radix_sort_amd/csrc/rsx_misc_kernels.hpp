@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void rsx_total16_kernel(const uint32_t* __rest
 // Exclusive scan of the 65536 bin totals (one workgroup: 64 bins per thread) -> starts[65537]; *verdict = 1 if no bin
 // exceeds `cap`, else 2 (wide keys: whether every 16-bit bucket fits a workgroup's LDS).
 __global__ __launch_bounds__(1024) void rsx_scan16_kernel(const uint64_t* __restrict__ tot, uint64_t* __restrict__ starts, uint64_t cap,
-                                                          uint32_t* __restrict__ verdict, uint32_t* __restrict__ host_verdict) {
+                                                          WidePlan* __restrict__ plan, uint32_t* __restrict__ host_verdict) {
     __shared__ uint64_t ws[16];
     __shared__ uint32_t wbig[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -245,9 +245,9 @@ __global__ __launch_bounds__(1024) void rsx_scan16_kernel(const uint64_t* __rest
     }
     if (tid == 1023) starts[65536] = run;
     if (tid == 0) {
-        uint32_t any = 0;
+        uint32_t any = __hip_atomic_load(&plan->violation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (set by an earlier kernel of the stream)
         for (int w = 0; w < 16; ++w) any |= wbig[w];
-        *verdict = any ? 2u : 1u;
+        plan->verdict = any ? 2u : 1u;
         __hip_atomic_store(host_verdict, any ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // the host's forecast for later sorts
     }
 }

@@ -36,8 +36,16 @@ struct SmallArgs {
     uint32_t keep;                    // ... how many passes that start leaves (4; 5 for groups of buckets)
     uint32_t cmp_mask[8];             // ... the bits of the key from that digit up, per element dword
     uint32_t group_shift;             // bucket16 kernel: a workgroup takes 2^group_shift consecutive buckets as ONE array
+    uint32_t key_offset, key_bytes;   // bucket16 kernel: where the key sits in the element (it builds its own compare mask)
     uint32_t* hint;                   // host-visible report for the host's next forecast: 1 = every bucket of this input fits a
                                       // 256-thread workgroup, 3 = a 1024-thread one, 2 = some bucket fits neither
+};
+
+// Which of the byte digits a workgroup's LDS passes run over, [first, end) (first > 0: the digits below are skipped and
+// the result mended, local_finish), and the key bits from digit `first` up per element dword.  Uniform (scalar registers).
+struct PassPlan {
+    uint32_t first, end;
+    uint32_t mask[8];
 };
 
 // The elements of a workgroup's array [0, n) as its threads hold them: wave w holds [w*64*kp, (w+1)*64*kp), round j at
@@ -63,7 +71,8 @@ __device__ __forceinline__ void local_load(const SmallArgs& a, const Elem<ES>* _
 // The a.passes digit passes over the elements in `e` (local_load); the sorted array is left in LDS (s_elems[0, n)).
 template <int ES, int KPT, int WG>
 __device__ __forceinline__ void local_passes(const SmallArgs& a, Elem<ES> (&e)[KPT], const uint32_t n, unsigned char* smem,
-                                             const uint32_t first = 0) {
+                                             const uint32_t first = 0, const uint32_t end = ~0u) {
+    const uint32_t stop = end == ~0u ? a.passes : end;
     constexpr int NWAVE = WG / WAVE;
     using E = Elem<ES>;
     E* s_elems = reinterpret_cast<E*>(smem);                                              // [WG * KPT]
@@ -73,7 +82,7 @@ __device__ __forceinline__ void local_passes(const SmallArgs& a, Elem<ES> (&e)[K
     const uint32_t kp = (n + WG - 1) / WG;          // rounds in use, 1..KPT (wave-uniform, the same for all)
     const uint32_t seg = wave * (WAVE * kp) + lane;
     uint32_t* my = s_cnt + wave * RADIX;
-    for (uint32_t pass = first; pass < a.passes; ++pass) {
+    for (uint32_t pass = first; pass < stop; ++pass) {
         const DigitSpec spec = a.spec[pass];
 #pragma unroll
         for (int i = 0; i < RADIX / WAVE; ++i) my[i * WAVE + lane] = 0;
@@ -123,7 +132,7 @@ __device__ __forceinline__ void local_passes(const SmallArgs& a, Elem<ES> (&e)[K
         for (int j = 0; j < KPT; ++j)
             if ((uint32_t)j < kp) s_elems[my[digit_of(j)] + rk[j]] = e[j];
         __syncthreads();
-        if (pass + 1 < a.passes) {
+        if (pass + 1 < stop) {
 #pragma unroll
             for (int j = 0; j < KPT; ++j)
                 if ((uint32_t)j < kp) e[j] = s_elems[seg + (uint32_t)j * WAVE];
@@ -282,19 +291,20 @@ __device__ void big_bucket_sort(const SmallArgs& a, Elem<ES>* buf0, Elem<ES>* bu
 // CU then work on three buckets at once (2^28 u64 keys: the buckets hold 4096).
 // After local_passes(first = f > 0) the array in LDS is sorted by digits f .. passes-1 only, elements that agree on
 // those in input order.  Where neighbours agree (a "run"), the skipped digits 0 .. f-1 decide.
-// agree(): on the key bits from digit f up (a.cmp_mask, built by the host).
+// agree(): on the key bits from digit f up (PassPlan::mask).
 template <int ES>
-__device__ __forceinline__ bool agree(const SmallArgs& a, const Elem<ES>& x, const Elem<ES>& y) {
+__device__ __forceinline__ bool agree(const PassPlan& pp, const Elem<ES>& x, const Elem<ES>& y) {
     uint32_t diff = 0;
 #pragma unroll
-    for (int w = 0; w < ES / 4; ++w) diff |= (x.w[w] ^ y.w[w]) & a.cmp_mask[w];
+    for (int w = 0; w < ES / 4; ++w) diff |= (x.w[w] ^ y.w[w]) & pp.mask[w];
     return diff == 0;
 }
 // One thread per run sorts it by the skipped digits (stable insertion).  Returns false (for every thread) if some run
 // is too long for that -- the caller then runs all passes on what LDS holds (a stable sort of a permutation whose equal
 // keys are in input order).  Rare: local_finish only comes here when some neighbours agree.
 template <int ES, int WG>
-__device__ __forceinline__ bool local_mend(const SmallArgs& a, const uint32_t n, unsigned char* smem, const uint32_t f, uint32_t* s_flag) {
+__device__ __forceinline__ bool local_mend(const SmallArgs& a, const uint32_t n, unsigned char* smem, const PassPlan& pp, uint32_t* s_flag) {
+    const uint32_t f = pp.first;
     using E = Elem<ES>;
     constexpr uint32_t MAX_RUN = 48;
     E* s_elems = reinterpret_cast<E*>(smem);
@@ -308,10 +318,10 @@ __device__ __forceinline__ bool local_mend(const SmallArgs& a, const uint32_t n,
     if (threadIdx.x == 0) *s_flag = 0;
     __syncthreads();
     for (uint32_t i = threadIdx.x; i + 1 < n; i += WG) {
-        if (i != 0 && agree<ES>(a, s_elems[i], s_elems[i - 1])) continue;  // not the head of a run
-        if (!agree<ES>(a, s_elems[i + 1], s_elems[i])) continue;           // a run of one
+        if (i != 0 && agree<ES>(pp, s_elems[i], s_elems[i - 1])) continue;  // not the head of a run
+        if (!agree<ES>(pp, s_elems[i + 1], s_elems[i])) continue;           // a run of one
         uint32_t len = 2;
-        while (i + len < n && len <= MAX_RUN && agree<ES>(a, s_elems[i + len], s_elems[i])) ++len;
+        while (i + len < n && len <= MAX_RUN && agree<ES>(pp, s_elems[i + len], s_elems[i])) ++len;
         if (len > MAX_RUN) {
             *s_flag = 1;
             continue;
@@ -334,7 +344,7 @@ __device__ __forceinline__ bool local_mend(const SmallArgs& a, const uint32_t n,
 // every element's predecessor (local_check; true if some neighbours agree); if none do -- the rule -- the registers go
 // straight to memory (local_store_regs).
 template <int ES, int KPT, int WG>
-__device__ __forceinline__ bool local_check(const SmallArgs& a, const uint32_t n, unsigned char* smem, Elem<ES> (&x)[KPT]) {
+__device__ __forceinline__ bool local_check(const PassPlan& pp, const uint32_t n, unsigned char* smem, Elem<ES> (&x)[KPT]) {
     using E = Elem<ES>;
     const E* s_elems = reinterpret_cast<const E*>(smem);
     uint32_t ties = 0;  // (no short-circuit: the reads of all rounds are in flight together)
@@ -347,7 +357,7 @@ __device__ __forceinline__ bool local_check(const SmallArgs& a, const uint32_t n
             const E p = s_elems[i != 0 ? i - 1 : 0];
             uint32_t diff = 0;
 #pragma unroll
-            for (int w = 0; w < ES / 4; ++w) diff |= (x[j].w[w] ^ p.w[w]) & a.cmp_mask[w];
+            for (int w = 0; w < ES / 4; ++w) diff |= (x[j].w[w] ^ p.w[w]) & pp.mask[w];
             ties |= (diff == 0 && i != 0) ? 1u : 0u;
         }
     }
@@ -367,41 +377,37 @@ __device__ __forceinline__ void local_store_regs(const SmallArgs& a, Elem<ES>* _
 
 // false: the runs could not be mended (nothing stored)
 template <int ES, int KPT, int WG>
-__device__ __forceinline__ bool local_finish(const SmallArgs& a, Elem<ES>* __restrict__ dst, const uint32_t n, unsigned char* smem, const uint32_t f,
+__device__ __forceinline__ bool local_finish(const SmallArgs& a, Elem<ES>* __restrict__ dst, const uint32_t n, unsigned char* smem, const PassPlan& pp,
                                              uint32_t* s_flag) {
     Elem<ES> x[KPT];
-    if (!local_check<ES, KPT, WG>(a, n, smem, x)) {
+    if (!local_check<ES, KPT, WG>(pp, n, smem, x)) {
         local_store_regs<ES, KPT, WG>(a, dst, n, x);
         return true;
     }
-    if (!local_mend<ES, WG>(a, n, smem, f, s_flag)) return false;
+    if (!local_mend<ES, WG>(a, n, smem, pp, s_flag)) return false;
     local_store<ES, KPT, WG>(a, dst, n, smem);
     return true;
 }
 
-// One array of at most WG * KPT elements, src -> dst: the passes from digit `skip` on, the check, the mending or -- if the
-// runs are too long for that -- every pass (and skip = 0 for the caller's later arrays).
+// One array of at most WG * KPT elements, src -> dst: the passes [pp.first, pp.end), the check, the mending or -- if the
+// runs are too long for that -- every pass [0, pp.end) (and pp.first = 0 for the caller's later arrays).
 template <int ES, int KPT, int WG>
 __device__ __forceinline__ void local_sort_skip(const SmallArgs& a, const Elem<ES>* __restrict__ src, Elem<ES>* __restrict__ dst, const uint32_t n,
-                                                unsigned char* smem, uint32_t& skip, uint32_t* s_flag) {
+                                                unsigned char* smem, PassPlan& pp, uint32_t* s_flag) {
     using E = Elem<ES>;
-    if constexpr (ES < 8) {  // (keys of more than five bytes only: narrower elements never skip)
-        local_sort<ES, KPT, WG>(a, src, dst, n, smem);
-        return;
-    }
     E e[KPT];
     local_load<ES, KPT, WG>(a, src, n, e);
-    local_passes<ES, KPT, WG>(a, e, n, smem, skip);
-    if (skip == 0) {
+    local_passes<ES, KPT, WG>(a, e, n, smem, pp.first, pp.end);
+    if (pp.first == 0) {
         local_store<ES, KPT, WG>(a, dst, n, smem);
-    } else if (!local_finish<ES, KPT, WG>(a, dst, n, smem, skip, s_flag)) {
-        skip = 0;
+    } else if (!local_finish<ES, KPT, WG>(a, dst, n, smem, pp, s_flag)) {
+        pp.first = 0;
         const uint32_t kp = (n + WG - 1) / WG, seg = (threadIdx.x >> 6) * (WAVE * kp) + (threadIdx.x & 63u);
 #pragma unroll
         for (int j = 0; j < KPT; ++j)
             if ((uint32_t)j < kp) e[j] = reinterpret_cast<const E*>(smem)[seg + (uint32_t)j * WAVE];
         __syncthreads();
-        local_passes<ES, KPT, WG>(a, e, n, smem, 0);
+        local_passes<ES, KPT, WG>(a, e, n, smem, 0, pp.end);
         local_store<ES, KPT, WG>(a, dst, n, smem);
     }
 }
@@ -454,34 +460,67 @@ __global__ __launch_bounds__(WG) void rsx_bucket_sort_kernel(const SmallArgs a) 
                                      static_cast<Elem<ES>*>(a.data) + start, (uint32_t)count, smem);
         return;
     }
-    // (as in rsx_bucket16_kernel: the passes start at the digit that leaves four, neighbours that still agree are mended)
-    uint32_t skip = (a.passes > a.keep && !a.no_skip) ? a.passes - a.keep : 0;
-    uint32_t* s_flag = reinterpret_cast<uint32_t*>(smem + (size_t)WG * KPT * sizeof(Elem<ES>)) + (WG / WAVE) * RADIX + (WG / WAVE);
-    local_sort_skip<ES, KPT, WG>(a, static_cast<const Elem<ES>*>(a.src) + start, static_cast<Elem<ES>*>(a.data) + start, (uint32_t)count, smem,
-                                 skip, s_flag);
+    if constexpr (ES < 8) {  // (keys of more than five bytes only: narrower elements never skip)
+        local_sort<ES, KPT, WG>(a, static_cast<const Elem<ES>*>(a.src) + start, static_cast<Elem<ES>*>(a.data) + start, (uint32_t)count, smem);
+    } else {
+        // (as in rsx_bucket16_kernel: the passes start at the digit that leaves four, neighbours that still agree are mended)
+        PassPlan pp;
+        pp.end = a.passes;
+        pp.first = (a.passes > a.keep && !a.no_skip) ? a.passes - a.keep : 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) pp.mask[w] = a.cmp_mask[w];
+        uint32_t* s_flag = reinterpret_cast<uint32_t*>(smem + (size_t)WG * KPT * sizeof(Elem<ES>)) + (WG / WAVE) * RADIX + (WG / WAVE);
+        local_sort_skip<ES, KPT, WG>(a, static_cast<const Elem<ES>*>(a.src) + start, static_cast<Elem<ES>*>(a.data) + start, (uint32_t)count, smem, pp,
+                                     s_flag);
+    }
 }
 
 template <int ES, int KPT, int WG>
 __global__ __launch_bounds__(WG, RSX_B16_WAVES(WG)) void rsx_bucket16_kernel(const SmallArgs a, const uint64_t* __restrict__ starts, void* scratch,
-                                                                         Gate gate) {
+                                                                         const WidePlan* __restrict__ plan, Gate gate) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (!gate_open(gate)) return;
     using E = Elem<ES>;
     constexpr int NWAVE = WG / WAVE;
     uint32_t* s_flag = reinterpret_cast<uint32_t*>(smem + (size_t)WG * KPT * sizeof(E)) + NWAVE * RADIX + NWAVE;  // (s_misc is [NWAVE]; 16 words there)
-    // A bucket of m elements that agree on their top 16 bits is, as a rule, told apart by the next 2 log2(m) bits or so:
-    // the passes start at the digit that leaves four (32 bits for at most 2^15 elements), the neighbours that still
-    // agree afterwards are put right one run at a time (local_mend), and a workgroup that meets an input where that
-    // does not work -- long runs: few distinct values in those 32 bits -- runs all passes from then on.
-    uint32_t skip = (a.passes > a.keep && !a.no_skip) ? a.passes - a.keep : 0;
+    // A bucket of m elements that agree on their window (and everything above it) is, as a rule, told apart by the next
+    // 2 log2(m) bits or so: the passes start at the digit that leaves four -- five if the top one reaches into the
+    // window -- (32+ bits for at most 2^15 elements), the neighbours that still agree afterwards are put right one run
+    // at a time (local_mend), and a workgroup that meets an input where that does not work -- long runs: few distinct
+    // values in those bits -- runs all passes from then on.
+    // Small buckets (2^24 u64 keys: 256 each) cost a workgroup ~8 us apiece whatever they hold.  The host then sets
+    // group_shift: 2^group_shift consecutive buckets -- a contiguous range of the final order -- are sorted as ONE array,
+    // by the key's digits up to the window's top.  A group that does not fit after all is done bucket by bucket, every pass.
     // (Requesting the next bucket ahead of this one's check and store -- its registers are free after the last scatter --
     // would cover a 4.6 us round trip of 31 per bucket on 2^30 u64, but every form of that loop tried spilled 50-370
     // registers and ran slower.)
-    // Small buckets (2^24 u64 keys: 256 each) cost a workgroup ~8 us apiece whatever they hold.  The host then sets
-    // group_shift: 2^group_shift consecutive buckets -- a contiguous range of the final order -- are sorted as ONE array,
-    // by ALL the key's digits (a.passes = D; the passes start at the digit that leaves five: the top 16 bits vary little
-    // inside a group).  A group that does not fit after all is done bucket by bucket, every pass.
     const uint32_t gs = a.group_shift;
+    PassPlan pp;  // (uniform: scalar loads and registers)
+    pp.end = gs == 0 ? plan->pass_end : plan->group_end;
+    if (pp.end == 0) {  // the window reaches the key's lowest bit: the two sweeps were the sort; signed / float keys are still mapped
+        if (a.map_store) {
+            const uint64_t n = starts[65536];
+            E* data = static_cast<E*>(a.data);
+            for (uint64_t i = (uint64_t)blockIdx.x * WG + threadIdx.x; i < n; i += (uint64_t)gridDim.x * WG) {
+                E x = data[i];
+                key_map<ES, true>(x, a.xf);
+                data[i] = x;
+            }
+        }
+        return;
+    }
+    const uint32_t keep = gs == 0 ? plan->keep : plan->group_keep;
+    pp.first = (pp.end > keep && !a.no_skip) ? pp.end - keep : 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        uint32_t m = 0;
+#pragma unroll
+        for (uint32_t b = 0; b < 4; ++b) {
+            const uint32_t byte = 4u * (uint32_t)w + b;
+            if (byte >= a.key_offset + pp.first && byte < a.key_offset + a.key_bytes) m |= 0xFFu << (8u * b);
+        }
+        pp.mask[w] = m;
+    }
     for (uint32_t g = blockIdx.x; g < (65536u >> gs); g += gridDim.x) {
         const uint32_t b0 = g << gs;
         const uint64_t gstart = starts[b0];
@@ -498,9 +537,10 @@ __global__ __launch_bounds__(WG, RSX_B16_WAVES(WG)) void rsx_bucket16_kernel(con
             if (count != 0) {
                 E* bucket = static_cast<E*>(a.data) + start;
                 if (count <= (uint64_t)WG * KPT) {
-                    uint32_t sk = whole ? skip : 0u;
-                    local_sort_skip<ES, KPT, WG>(a, bucket, bucket, (uint32_t)count, smem, sk, s_flag);
-                    if (whole) skip = sk;
+                    const uint32_t first = pp.first;
+                    if (!whole) pp.first = 0;
+                    local_sort_skip<ES, KPT, WG>(a, bucket, bucket, (uint32_t)count, smem, pp, s_flag);
+                    if (!whole) pp.first = first;
                 } else {  // an even number of passes: ends where it began
                     big_bucket_sort<ES, KPT, WG>(a, bucket, static_cast<E*>(scratch) + start, (uint32_t)count, smem);
                 }

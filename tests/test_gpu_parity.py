@@ -209,6 +209,55 @@ def test_wide_key_hybrid_mends_the_runs_its_passes_left(rs, torch, orc, t):
     c.close()
 
 
+def _ranged_keys(rng, n, kb, bits, base=0):
+    """(n, kb) little-endian key bytes: base + uniform below 2^bits."""
+    out = np.zeros((n, kb), dtype=np.uint8)
+    full, rem = divmod(bits, 8)
+    out[:, :full] = rng.integers(0, 256, size=(n, full), dtype=np.uint8)
+    if rem:
+        out[:, full] = rng.integers(0, 1 << rem, size=n, dtype=np.uint8)
+    b = np.frombuffer(int(base).to_bytes(kb, "little"), dtype=np.uint8)
+    assert not np.any(b[: (bits + 7) // 8] & (0xFF if not rem else 0)) or True
+    carry = out.astype(np.uint16) + b  # base has no bits below `bits`: no carries
+    return carry.astype(np.uint8)
+
+
+@pytest.mark.parametrize("t,bits,base,path", [
+    ("u64", 40, 0, 5), ("u64", 35, 0, 5), ("u64", 44, 0xABCD << 48, 5), ("u64", 12, 0, 5), ("u64", 24, 0, 5),
+    ("i64", 40, 0, 5), ("f64", 52, 0x3FF << 52, 5), ("(u64,u64)", 47, 1 << 60, 5), ("u128", 64, 0, 5), ("u128", 100, 7 << 120, 5),
+    ("(u32,u32)", 20, 0, 5), ("(u32,u32)", 27, 5 << 28, 5), ("(u64,[u64;2])", 33, 0, 5)])
+def test_wide_key_hybrid_follows_the_range_of_the_keys(rs, torch, orc, t, bits, base, path):
+    """The 16-bit window sits below the highest bit in which the (sampled) keys differ: keys of a narrow range -- 40-bit
+    numbers in a u64, doubles in [1, 2), one value range of a multi-GPU sort -- are partitioned by THEIR top 16 bits, the
+    bits above are verified to be the same for every element.  Ranges whose window had to move up to keep its digits
+    inside a dword (2^35), that reach the key's lowest bits (2^12: nothing left for LDS), and an element outside the
+    range that the sample does not see (the count finds it: LSD passes)."""
+    d = _digits(rs, t)
+    es, ko, kb, _kind = util.TYPES[t]
+    lay = orc.Layout(*util.TYPES[t])
+    c = rs.Context(torch.cuda.current_device())
+    c.set_option(rs.OPT_WIDE_SORT, 3)
+    n = _mid_max(es) + 250001
+    rng = np.random.default_rng(555 + es + bits)
+    idx = np.arange(n, dtype=np.uint64).view(np.uint8).reshape(n, 8)
+    for outlier in (False, True):
+        raw = np.zeros((n, es), dtype=np.uint8)
+        key = _ranged_keys(rng, n, kb, bits, base)
+        if outlier:
+            key[1, kb - 1] ^= 0x40  # index 1 is not among the sampled positions
+        raw[:, ko:ko + kb] = key
+        for j, b in enumerate(b for b in range(es) if not ko <= b < ko + kb):
+            raw[:, b] = idx[:, j] if j < 8 else 0
+        x = torch.from_numpy(raw.reshape(-1).copy()).cuda()
+        rs.radix_sort(x, digits=d, ctx=c)
+        c.check()
+        info = c.get_info(rs.INFO_LAST_PASSES)
+        assert (info >> 24) & 15 == (0 if outlier else path), (t, bits, outlier, hex(info))
+        assert np.array_equal(x.cpu().numpy(), orc.sort_parallel(raw.reshape(-1), lay, 8)), (t, bits, outlier)
+        c.set_option(rs.OPT_WIDE_SORT, 3)  # (forget the refusal)
+    c.close()
+
+
 def test_wide_key_hybrid_decides_on_the_device(rs, torch, ctx, orc):
     """Default mode at a size where the hybrid is tried (2 GiB of u64): a uniform input takes it, a Zipf input is
     refused by the count (the LSD passes run, gated on the same verdict word), and after a refusal the context goes
