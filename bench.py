@@ -55,10 +55,14 @@ WORKLOADS = {
     "u8-256m": ("u8", 28, "uniform", 0.0, "256M u8 uniform keys (counting path)"),
     "pairs-128m-u64u64": ("(u64,u64)", 27, "uniform", 0.0, "128M (u64,u64) pairs (reference bench type, main.rs:123)"),
     "u128-128m": ("u128", 27, "uniform", 0.0, "128M u128 uniform keys (16 digits)"),
+    "u64-40bit-256m": ("u64", 28, "uniform", 0.0, "256M u64 keys below 2^40 (uniform): the hybrid's window follows the keys' range"),
+    "u64-range-1b": ("u64", 30, "uniform", 0.0, "1B u64 keys of ONE of 32 value ranges (5 fixed top bits): what a rank sorts after a multi-GPU exchange"),
 }
+# workloads whose uniform keys are cut to a range after generation: name -> (bits, base)
+KEY_RANGE = {"u64-40bit-256m": (40, 0), "u64-range-1b": (59, 0x5 << 59)}
 HEADLINE = "c3-1b-u64"  # the largest single-GPU configuration in BASELINE.json's configs (configs[2])
 EXTRA_DEFAULT = ["target-1b-u32", "c2-256m-u32", "c4-slice-512m-u32", "zipf-256m-u32", "step16-256m-u32", "zipf-256m-u64", "c5-slice-128m-pairs-zipf",
-                 "pairs-128m-u64u64", "u128-128m", "c1-1m-u32", "u16-256m"]
+                 "pairs-128m-u64u64", "u128-128m", "u64-40bit-256m", "c1-1m-u32", "u16-256m"]
 
 
 PATH_NAMES = ["general passes", "one-launch sort", "middle-size bucket split", "one-byte counting", "two-byte counting",
@@ -93,6 +97,9 @@ def run_single(rs, torch, ctx, wl, steps, warmup, seed0=0x5EED0000, profile=True
 
     def fill(i, b):
         ctx.generate_device(b.data_ptr(), n, d, gen_id(rs, gen), seed0 + i, param, 0, stream)
+        if wl in KEY_RANGE:  # (8-byte keys only)
+            bits, base = KEY_RANGE[wl]
+            b.view(torch.int64).bitwise_and_((1 << bits) - 1).bitwise_or_(base)
 
     for i in range(warmup):
         fill(1000 + i, bufs[0])
