@@ -26,7 +26,7 @@ for wl in $wls; do
 import csv, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for row in csv.DictReader(open(sys.argv[1])):
-    k = row["Kernel_Name"].split("(")[0][-64:]
+    k = row["Kernel_Name"].split("(")[0][-96:]
     acc[k][row["Counter_Name"]] += float(row["Counter_Value"]); cnt[(k, row["Counter_Name"])] += 1
 for k in sorted(acc):
     if any(w in k for w in ("sweep", "hist", "expand", "bucket", "tile", "count16", "total16")):
