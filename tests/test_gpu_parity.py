@@ -900,6 +900,13 @@ def test_config5_1b_pairs_zipf_sharded_full_size(rs, torch):
     _full_config_sharded(rs, torch, "(u64,u64)", 30, rs.GEN_ZIPF, 1.0, 0x5EED0005)
 
 
+@pytest.mark.parametrize("t,logn", [("u64", 28), ("(u64,u64)", 27)])
+def test_uniform_wide_keys_sharded(rs, torch, t, logn):
+    """Uniform 8-byte keys over 8 slices: every slice sorts VALUE RANGES (three fixed top bits and more), which take the
+    wide-key hybrid with its window below those bits; bit for bit the single sort (itself a hybrid sort of the whole)."""
+    _full_config_sharded(rs, torch, t, logn, rs.GEN_UNIFORM, 0.0, 0x5EED0007)
+
+
 def test_one_context_two_streams(rs, torch, orc):
     """one context used from two streams -- the second stream's sort must wait (on the device)
     for the first one's: they share the context's count matrices, tickets and status words."""
