@@ -725,16 +725,18 @@ def test_many_sorts_one_context_and_graph_capture(rs, torch, ctx):
     assert torch.equal(work.cpu(), torch.sort(src.cpu()).values)
 
 
-@pytest.mark.parametrize("n", [300001, 5000001])
-def test_graph_replay_with_changing_inputs(rs, torch, orc, n):
+@pytest.mark.parametrize("t,n", [("u32", 300001), ("u32", 5000001), ("u64", 5000001), ("(u64,u64)", 3000001), ("f64", 4500001)])
+def test_graph_replay_with_changing_inputs(rs, torch, orc, t, n):
     """A captured sort is replayed on different inputs: the middle-size path is captured as the bucket split (the
     forecast is taken at capture time) and a replay on a skewed input must still be right (oversized buckets through
-    memory); the general path under capture uses the control block that it zeroes itself, replay after replay."""
+    memory); the general path under capture uses the control block that it zeroes itself, replay after replay; wide keys
+    above the middle sizes are captured as BOTH sequences of the hybrid, and every replay decides on the device which
+    one runs (uniform: the hybrid, with the window where that input's keys differ; Zipf, equal keys: the LSD passes)."""
     c = rs.Context(torch.cuda.current_device())
-    d = rs.PRIMITIVES["u32"]
-    lay = orc.Layout(*util.TYPES["u32"])
+    d = _digits(rs, t)
+    lay = orc.Layout(*util.TYPES[t])
     c.reserve(n, d)
-    inputs = [util.make_input("u32", n, dist, seed=40 + i) for i, dist in enumerate(("uniform", "zipf", "uniform", "equal", "sorted"))]
+    inputs = [util.make_input(t, n, dist, seed=40 + i) for i, dist in enumerate(("uniform", "zipf", "uniform", "equal", "sorted"))]
     src = torch.from_numpy(inputs[0].copy()).cuda()
     work, tmp = torch.empty_like(src), torch.empty_like(src)
     s = torch.cuda.Stream()
