@@ -166,13 +166,14 @@ __global__ __launch_bounds__(512) void rsx_tilescatter_kernel(const MidArgs a) {
     }
 }
 
-// ---- wide keys, large arrays: two passes through memory for the top 16 bits, the rest in LDS ---------------------
-// Eight-byte keys take eight sweeps of 2 n s bytes each.  A pass INSIDE LDS (rsx_small_kernel.hpp local_sort) costs a
-// workgroup about half of what a sweep costs it per key -- no HBM, no look-back --, so when the top 16 bits of the
-// mapped key spread the array over their 65536 buckets evenly enough for every bucket to fit a workgroup's LDS, the
-// sort is: count those 16 bits (this kernel + rsx_total16_kernel + rsx_scan16_kernel), two ordinary LSD sweeps on
-// digits D-2 and D-1 (after which every bucket is contiguous and in input order), and rsx_bucket16_kernel: every
-// bucket sorted by its remaining D-2 digits in LDS.  Same bytes as D LSD passes (the stable sort by the whole key).
+// ---- wide keys: two passes through memory for a 16-bit window of the key, the rest in LDS ------------------------------
+// Eight-byte keys take eight sweeps of 2 n s bytes each.  A pass INSIDE LDS (rsx_small_kernel.hpp local_passes) costs a
+// workgroup a fraction of what a sweep costs it per key -- no HBM, no look-back --, so when 16 bits of the mapped key
+// (the window: below the highest bit in which the keys differ) spread the array over their 65536 buckets evenly enough
+// for every bucket to fit a workgroup's LDS, the sort is: place the window (rsx_wideplan_kernel), count it
+// (rsx_count16top_kernel + rsx_total16_kernel + rsx_scan16_kernel), two LSD sweeps on its two digits (after which every
+// bucket is contiguous and in input order), and rsx_bucket16_kernel: every bucket sorted by the digits below the window
+// in LDS.  Same bytes as D LSD passes (the bits above the window are the same in every key: verified by the count).
 //
 // rsx_wideplan_kernel: one workgroup looks at 16384 elements spread over the array (and the last one), finds the highest
 // bit in which their mapped keys differ from the first element's, and places the window: the 16 bits from there down

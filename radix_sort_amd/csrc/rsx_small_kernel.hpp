@@ -5,6 +5,11 @@
 //                          buckets of its MOST significant digit (a stable partition: bucket v sits at its final
 //                          position range, in input order); workgroup v sorts bucket v by the remaining D-1
 //                          digits.  Two trips through memory instead of D, and one launch instead of D-1.
+//  rsx_bucket16_kernel     the last stage of the wide-key hybrid (rsx_mid_kernels.hpp): two sweeps have partitioned
+//                          the array by a 16-bit window of the key; persistent workgroups sort the 65536 buckets (or
+//                          groups of small ones) by the digits below it.
+//  Both bucket kernels start their passes at the digit that leaves four or five (PassPlan) and mend the few
+//  neighbours that still agree afterwards by the skipped digits (local_finish, local_mend).
 //
 // The general path costs a memset, a count kernel and D sweeps whatever the size (>= 10 us each: a sweep of one
 // tile still walks its roll call, cursors and flush): 70 us for 1000 u32 keys, 110 us for 2^20.  Here the
@@ -284,11 +289,11 @@ __device__ void big_bucket_sort(const SmallArgs& a, Elem<ES>* buf0, Elem<ES>* bu
 // waves per SIMD the bucket16 kernel is compiled for: its LDS lets 2 workgroups of 512 threads (4 waves per SIMD) or 3
 // of 256 (3 waves per SIMD) share a CU, if their registers do
 #define RSX_B16_WAVES(WG) ((WG) >= 512 ? 4 : 3)
-// Wide keys, large arrays (rsx_mid_kernels.hpp, rsx_count16top_kernel): the array is partitioned by the top 16 bits of
-// the mapped key; starts[b] .. starts[b + 1] is bucket b.  Persistent workgroups take the buckets round-robin and sort
-// each by the remaining digits in LDS, in place; one that does not fit goes through memory (`scratch`, same offsets).
-// WG: 1024 threads (one workgroup per CU), or 256 where the average bucket fits a quarter of that: three workgroups per
-// CU then work on three buckets at once (2^28 u64 keys: the buckets hold 4096).
+// Wide keys (rsx_mid_kernels.hpp, rsx_count16top_kernel): the array is partitioned by a 16-bit window of the mapped key
+// (WidePlan); starts[b] .. starts[b + 1] is bucket b.  Persistent workgroups take the buckets round-robin and sort each
+// by the digits below the window in LDS, in place; one that does not fit goes through memory (`scratch`, same offsets).
+// WG: 1024 threads (one workgroup per CU), 512 (two) or 256 (three) by the average bucket.
+//
 // After local_passes(first = f > 0) the array in LDS is sorted by digits f .. passes-1 only, elements that agree on
 // those in input order.  Where neighbours agree (a "run"), the skipped digits 0 .. f-1 decide.
 // agree(): on the key bits from digit f up (PassPlan::mask).
