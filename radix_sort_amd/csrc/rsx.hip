@@ -412,8 +412,14 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
             LaunchTimer lt(ctx, RSX_PROF_SCAN, st);
             hipLaunchKernelGGL(rsx_total16_kernel, dim3(256), dim3(256), 0, st, static_cast<const uint32_t*>(d_tmp), (uint32_t)parts, ctx->ovf16, tot, BT);
             RSX_HIP(hipGetLastError());
-            hipLaunchKernelGGL(rsx_scan16_kernel, dim3(1), dim3(1024), 0, st, tot, starts,
-                               ctx->wide_mode == 2 ? ~0ull : (uint64_t)bucket_cap_for(es), plan, ctx->host_err_dev + 9);
+            // which form of the bucket kernel runs is the device's choice too (launch_bucket16 enqueues them all):
+            // groups of small buckets are on offer when the AVERAGE bucket is small (keys of at least 8 bytes)
+            const uint64_t cap1024 = bucket_cap_for(es), avg = (uint64_t)n / 65536u;
+            uint32_t gs = 0;
+            if (D >= 8 && ctx->bucket_group)
+                while (gs < 6 && (avg << (gs + 1)) <= cap1024 / 2 * 3 / 4) ++gs;
+            hipLaunchKernelGGL(rsx_scan16_kernel, dim3(1), dim3(1024), 0, st, tot, starts, cap1024 / 4, cap1024 / 2, cap1024, gs >= 2 ? gs : 0u,
+                               ctx->wide_mode == 2 ? 1u : 0u, plan, ctx->host_err_dev + 9);
             RSX_HIP(hipGetLastError());
         }
         rc = begin_control(ctx, st, geom, false);
@@ -421,7 +427,7 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
         const CleanList clean = ctx->clean;  // whichever count kernel runs does the cleaning
         ctx->cb_last = ctx->cb;
         // sequence 1 (verdict 1): LSD passes on digits D-2 and D-1, then every 16-bit bucket in LDS
-        ctx->gate = Gate{verdict, 1u};
+        ctx->gate = Gate{verdict, VERDICT_PATH_MASK, VERDICT_HYBRID};
         if (k > 0) {
             rc = marginal16_dispatch(ctx, static_cast<const uint32_t*>(d_tmp), (uint32_t)parts, k, geom, L, J_of(ctx, 0), J_of(ctx, 1), st);
         } else {  // (forced mode: counters may have overflowed; a count kernel of its own, its digit from the plan)
@@ -445,11 +451,11 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
         if (rc == RSX_OK) rc = bucket16_dispatch(ctx, d_data, d_tmp, n, L, starts, plan, st);
         // sequence 2 (verdict 2): the D LSD passes
         if (rc == RSX_OK) {
-            ctx->gate = Gate{verdict, 2u};
+            ctx->gate = Gate{verdict, VERDICT_PATH_MASK, VERDICT_LSD};
             ctx->clean = clean;
             rc = lsd_passes(ctx, d_data, d_tmp, n, L, geom, false, 0, st);
         }
-        ctx->gate = Gate{nullptr, 0u};
+        ctx->gate = Gate{nullptr, 0u, 0u};
         if (rc) return rc;
         ctx->last_sort_passes = D;
         ctx->last_path = 5;
@@ -733,7 +739,7 @@ int rsx_ctx_get_info(rsx_ctx* ctx, int what, uint64_t* out) try {
             if (path == 5 && ctx->wide_buf) {  // both sequences were enqueued: the device's verdict says which one ran
                 uint32_t verdict = 0;
                 RSX_HIP(hipMemcpy(&verdict, reinterpret_cast<char*>(ctx->wide_buf) + WIDE_PLAN_OFFSET, sizeof verdict, hipMemcpyDeviceToHost));
-                if (verdict == 1u) passes = 2;
+                if ((verdict & VERDICT_PATH_MASK) == VERDICT_HYBRID) passes = 2;
                 else path = 0;
             }
             for (uint32_t p = 0; p < passes && p < (uint32_t)MAX_PASSES; ++p) {

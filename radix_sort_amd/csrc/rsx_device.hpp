@@ -282,15 +282,20 @@ struct CleanList {
 };
 // Large arrays of wide keys are enqueued as TWO alternative kernel sequences (the 16-bit bucket hybrid and the LSD passes);
 // which one runs is decided on the device by rsx_scan16_kernel: a gated kernel returns at once unless *word == value
-// (word == null: no gate).  A launch that returns at once costs ~5 us, nothing beside these sorts' milliseconds.
+// ((*word & mask) == value; word == null: no gate).  A launch that returns at once costs ~5 us, nothing beside these sorts' milliseconds.
 struct Gate {
     const uint32_t* word;
-    uint32_t value;
+    uint32_t mask, value;
 };
 __device__ __forceinline__ bool gate_open(const Gate& g) {
     if (g.word == nullptr) return true;
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(g.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == g.value;
+    return ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(g.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & g.mask) == g.value;
 }
+// The verdict word of the wide-key hybrid (WidePlan::verdict): bit 0 the hybrid runs, bit 1 the LSD passes; with bit 0,
+// bits 4-5 say which form of the bucket kernel (all are enqueued, each behind its own gate): the smallest workgroup that
+// holds all but a handful of the buckets.
+constexpr uint32_t VERDICT_HYBRID = 1u, VERDICT_LSD = 2u, VERDICT_PATH_MASK = 3u;
+constexpr uint32_t VERDICT_WG256 = 0x00u, VERDICT_WG512 = 0x10u, VERDICT_WG1024 = 0x20u, VERDICT_GROUPS = 0x30u, VERDICT_FORM_MASK = 0x30u;
 
 // The plan of a wide-key hybrid sort, made on the device from a sample of the array (rsx_wideplan_kernel) and read by
 // every kernel of the hybrid: WHICH 16 bits of the mapped key the array is partitioned by -- the two 8-bit digits below
@@ -298,14 +303,14 @@ __device__ __forceinline__ bool gate_open(const Gate& g) {
 // above are the same for all, which rsx_count16top_kernel verifies on every element) -- and which byte digits are left
 // for the LDS passes.
 struct WidePlan {
-    uint32_t verdict;     // rsx_scan16_kernel: 1 the hybrid runs, 2 the LSD passes (the Gate word of both sequences)
+    uint32_t verdict;     // rsx_scan16_kernel: VERDICT_* (the Gate word of both sequences)
     uint32_t violation;   // some element differs from the sample above the window (or the sample cannot place one): refuse
     uint32_t pass_end;    // single buckets: the LDS passes are byte digits [pass_end - keep or 0, pass_end) of the key
     uint32_t keep;
     uint32_t group_end;   // groups of buckets: digits [group_end - group_keep or 0, group_end)
     uint32_t group_keep;
     uint32_t window_top;  // key bit index of the window's top bit (diagnostic)
-    uint32_t pad;
+    uint32_t group_shift; // rsx_scan16_kernel: groups of 2^group_shift buckets (the largest the host offers whose groups fit)
     DigitSpec specs[3];   // [0] low, [1] high digit of the window (plain digits of the MAPPED key); [2] filler (sweeps read pairs)
     uint32_t ref[8];      // the mapped first element
     uint32_t himask[8];   // key bits above the window, per element dword

@@ -83,7 +83,7 @@ struct rsx_ctx {
     void* pinned[4] = {nullptr, nullptr, nullptr, nullptr};  // ring of pinned bounce chunks
     hipEvent_t copy_event[4] = {nullptr, nullptr, nullptr, nullptr};
     // multi-GPU driver (rsx_sort_sharded): per-slice stream and splitter-search scratch, made once
-    rsx::Gate gate = {nullptr, 0};  // set around the launches of a gated kernel sequence (wide keys)
+    rsx::Gate gate = {nullptr, 0, 0};  // set around the launches of a gated kernel sequence (wide keys)
     uint32_t wide_skip = 0;     // sorts to go without trying the wide-key hybrid (the last try was refused on the device)
     char* wide_buf = nullptr;   // wide-key hybrid: bin totals [65536] u64, bin-block sums [256] u64, bucket starts [65537] u64, verdict u32
     uint32_t wide_mode = 1;     // RSX_OPT_WIDE_SORT: 0 off, 1 auto, 2 always, 3 auto without the size floor

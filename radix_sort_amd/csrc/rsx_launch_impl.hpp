@@ -425,6 +425,17 @@ int launch_marginal16(rsx_ctx* ctx, const uint32_t* P, uint32_t parts, uint32_t 
     return RSX_OK;
 }
 
+// groups of 2^gs small buckets (0: none): about 3/4 of what a 512-thread workgroup of the bucket kernel holds
+template <int ES>
+uint32_t bucket16_group_shift(rsx_ctx* ctx, size_t n, const rsx_layout* L) {
+    constexpr int KPT = bucket_kpt_for(ES);
+    const uint64_t avg = (uint64_t)n / 65536u;
+    uint32_t gs = 0;
+    if (L->key_bytes >= 8 && ctx->bucket_group)
+        while (gs < 6 && (avg << (gs + 1)) <= (uint64_t)512 * KPT * 3 / 4) ++gs;
+    return gs >= 2 ? gs : 0;
+}
+
 template <int ES>
 int launch_bucket16(rsx_ctx* ctx, void* data, void* scratch, size_t n, const rsx_layout* L, const uint64_t* starts, const WidePlan* plan,
                     hipStream_t st) {
@@ -452,31 +463,32 @@ int launch_bucket16(rsx_ctx* ctx, void* data, void* scratch, size_t n, const rsx
         a.key_offset = L->key_offset;
         a.key_bytes = L->key_bytes;
         LaunchTimer lt(ctx, RSX_PROF_OTHER, st);
-        // workgroup size by the AVERAGE bucket (a few buckets above the capacity go through memory): 256, 512 or 1024
-        // threads x KPT elements, as many workgroups per CU as their LDS allows (3-4, 2, 1)
+        // Every form the device's verdict can name is enqueued behind its own gate (rsx_scan16_kernel picks the smallest
+        // workgroup that holds all but a handful of THIS input's buckets; a form whose workgroup cannot even hold the
+        // average bucket is not enqueued): 256, 512 or 1024 threads x KPT elements, as many workgroups per CU as LDS and
+        // registers allow (3, 2, 1); small buckets in groups of 2^gs, about 3/4 of what a 512-thread workgroup holds,
+        // sorted by all digits up to the window's top (keys of at least 8 bytes).
         const uint64_t avg = (uint64_t)n / 65536u;
-        auto go = [&](auto wgc) {
+        const uint32_t gs = bucket16_group_shift<ES>(ctx, n, L);
+        const Gate base = ctx->gate;  // (null word: no gates -- never the case for this kernel)
+        auto go = [&](auto wgc, uint32_t form, uint32_t group_shift) {
             constexpr int WGS = decltype(wgc)::value;
+            SmallArgs b = a;
+            b.group_shift = group_shift;
+            if (group_shift) b.passes = L->key_bytes;
             const size_t lds = (size_t)WGS * KPT * ES + (WGS / 64) * RADIX * sizeof(uint32_t) + 64 + 3 * RADIX * sizeof(uint32_t);
             auto kern = rsx_bucket16_kernel<ES, KPT, WGS>;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             int per_cu = (int)((size_t)163840 / lds);
             if (per_cu < 1) per_cu = 1;
             if (per_cu > 4 * RSX_B16_WAVES(WGS) * 64 / WGS) per_cu = 4 * RSX_B16_WAVES(WGS) * 64 / WGS;
-            hipLaunchKernelGGL(kern, dim3((uint32_t)(ctx->num_cu * per_cu)), dim3(WGS), lds, st, a, starts, scratch, plan, ctx->gate);
+            const Gate g{base.word, VERDICT_PATH_MASK | VERDICT_FORM_MASK, VERDICT_HYBRID | form};
+            hipLaunchKernelGGL(kern, dim3((uint32_t)(ctx->num_cu * per_cu)), dim3(WGS), lds, st, b, starts, scratch, plan, g);
         };
-        // small buckets: groups of 2^gs consecutive buckets of about 3/4 of what a 512-thread workgroup holds, sorted by
-        // all D digits (keys of at least 8 bytes: five passes and a mend instead of four per bucket)
-        uint32_t gs = 0;
-        if (L->key_bytes >= 8 && ctx->bucket_group)
-            while (gs < 7 && (avg << (gs + 1)) <= (uint64_t)512 * KPT * 3 / 4) ++gs;
-        if (gs >= 2) {
-            a.group_shift = gs;
-            a.passes = L->key_bytes;
-            go(std::integral_constant<int, 512>{});
-        } else if (avg <= (uint64_t)256 * KPT) go(std::integral_constant<int, 256>{});
-        else if (avg <= (uint64_t)512 * KPT) go(std::integral_constant<int, 512>{});
-        else go(std::integral_constant<int, 1024>{});
+        if (gs >= 2) go(std::integral_constant<int, 512>{}, VERDICT_GROUPS, gs);
+        if (avg <= (uint64_t)256 * KPT) go(std::integral_constant<int, 256>{}, VERDICT_WG256, 0);
+        if (avg <= (uint64_t)512 * KPT) go(std::integral_constant<int, 512>{}, VERDICT_WG512, 0);
+        go(std::integral_constant<int, 1024>{}, VERDICT_WG1024, 0);
         RSX_HIP(hipGetLastError());
         return RSX_OK;
     }

@@ -216,16 +216,30 @@ __global__ __launch_bounds__(256) void rsx_total16_kernel(const uint32_t* __rest
 
 // Exclusive scan of the 65536 bin totals (one workgroup: 64 bins per thread) -> starts[65537]; *verdict = 1 if no bin
 // exceeds `cap`, else 2 (wide keys: whether every 16-bit bucket fits a workgroup's LDS).
-__global__ __launch_bounds__(1024) void rsx_scan16_kernel(const uint64_t* __restrict__ tot, uint64_t* __restrict__ starts, uint64_t cap,
+__global__ __launch_bounds__(1024) void rsx_scan16_kernel(const uint64_t* __restrict__ tot, uint64_t* __restrict__ starts, uint64_t cap256,
+                                                          uint64_t cap512, uint64_t cap1024, uint32_t gs_max, uint32_t forced,
                                                           WidePlan* __restrict__ plan, uint32_t* __restrict__ host_verdict) {
     __shared__ uint64_t ws[16];
-    __shared__ uint32_t wbig[16];
+    __shared__ uint32_t wover[16][3 + 8];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint64_t mine = 0, big = 0;
+    uint64_t mine = 0;
+    uint32_t o256 = 0, o512 = 0, o1024 = 0;  // buckets above what a workgroup of 256 / 512 / 1024 threads holds
+    uint32_t og[7] = {0, 0, 0, 0, 0, 0, 0};  // og[g]: groups of 2^g consecutive buckets above what 512 threads hold (g <= 6: inside my 64 bins)
+    uint64_t gsum[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int k = 0; k < 64; ++k) {
         const uint64_t c = tot[(size_t)tid * 64 + k];
         mine += c;
-        big = c > big ? c : big;
+        o256 += c > cap256 ? 1u : 0u;
+        o512 += c > cap512 ? 1u : 0u;
+        o1024 += c > cap1024 ? 1u : 0u;
+#pragma unroll
+        for (int g = 2; g <= 6; ++g) {
+            gsum[g] += c;
+            if (((k + 1) & ((1 << g) - 1)) == 0) {
+                og[g] += gsum[g] > cap512 ? 1u : 0u;
+                gsum[g] = 0;
+            }
+        }
     }
     uint64_t x = mine;
 #pragma unroll
@@ -233,9 +247,22 @@ __global__ __launch_bounds__(1024) void rsx_scan16_kernel(const uint64_t* __rest
         const uint64_t y = __shfl_up(x, o);
         if (lane >= (uint32_t)o) x += y;
     }
-    const uint64_t over = __ballot(big > cap);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        o256 += __shfl_xor(o256, o);
+        o512 += __shfl_xor(o512, o);
+        o1024 += __shfl_xor(o1024, o);
+#pragma unroll
+        for (int g = 2; g <= 6; ++g) og[g] += __shfl_xor(og[g], o);
+    }
     if (lane == 63) ws[wave] = x;
-    if (lane == 0) wbig[wave] = over != 0 ? 1u : 0u;
+    if (lane == 0) {
+        wover[wave][0] = o256;
+        wover[wave][1] = o512;
+        wover[wave][2] = o1024;
+#pragma unroll
+        for (int g = 2; g <= 6; ++g) wover[wave][3 + g] = og[g];
+    }
     __syncthreads();
     uint64_t run = x - mine;
     for (uint32_t w = 0; w < wave; ++w) run += ws[w];
@@ -245,10 +272,33 @@ __global__ __launch_bounds__(1024) void rsx_scan16_kernel(const uint64_t* __rest
     }
     if (tid == 1023) starts[65536] = run;
     if (tid == 0) {
-        uint32_t any = __hip_atomic_load(&plan->violation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (set by an earlier kernel of the stream)
-        for (int w = 0; w < 16; ++w) any |= wbig[w];
-        plan->verdict = any ? 2u : 1u;
-        __hip_atomic_store(host_verdict, any ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // the host's forecast for later sorts
+        uint32_t n256 = 0, n512 = 0, n1024 = 0;
+        for (int w = 0; w < 16; ++w) {
+            n256 += wover[w][0];
+            n512 += wover[w][1];
+            n1024 += wover[w][2];
+        }
+        // The smallest workgroup that holds all but a handful of the buckets (those few go through memory, one workgroup
+        // each: tolerable for buckets of its own size class, not for what exceeds the largest workgroup -- then the LSD
+        // passes run, unless the hybrid is forced).  Small buckets in groups if the host's average says so and no bucket
+        // is larger than a group's workgroup: the largest group size (up to the host's) whose groups fit.
+        constexpr uint32_t FEW = 8;
+        const uint32_t violation = __hip_atomic_load(&plan->violation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (set by an earlier kernel of the stream)
+        uint32_t gshift = 0;  // the largest group size on offer whose groups (all but a handful) fit their workgroup
+        for (uint32_t g = gs_max <= 6u ? gs_max : 6u; g >= 2u && gshift == 0u; --g) {
+            uint32_t over = 0;
+            for (int w = 0; w < 16; ++w) over += wover[w][3 + g];
+            if (over <= FEW) gshift = g;
+        }
+        plan->group_shift = gshift;
+        uint32_t v;
+        if (violation != 0 || (n1024 != 0 && !forced)) v = VERDICT_LSD;
+        else if (gshift != 0 && n512 == 0) v = VERDICT_HYBRID | VERDICT_GROUPS;
+        else if (n256 <= FEW) v = VERDICT_HYBRID | VERDICT_WG256;
+        else if (n512 <= FEW) v = VERDICT_HYBRID | VERDICT_WG512;
+        else v = VERDICT_HYBRID | VERDICT_WG1024;
+        plan->verdict = v;
+        __hip_atomic_store(host_verdict, (v & VERDICT_HYBRID) ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // the host's forecast for later sorts
     }
 }
 

@@ -499,7 +499,7 @@ __global__ __launch_bounds__(WG, RSX_B16_WAVES(WG)) void rsx_bucket16_kernel(con
     // (Requesting the next bucket ahead of this one's check and store -- its registers are free after the last scatter --
     // would cover a 4.6 us round trip of 31 per bucket on 2^30 u64, but every form of that loop tried spilled 50-370
     // registers and ran slower.)
-    const uint32_t gs = a.group_shift;
+    const uint32_t gs = a.group_shift != 0 ? plan->group_shift : 0;  // (the host offers groups up to 2^a.group_shift; rsx_scan16_kernel chose)
     PassPlan pp;  // (uniform: scalar loads and registers)
     pp.end = gs == 0 ? plan->pass_end : plan->group_end;
     if (pp.end == 0) {  // the window reaches the key's lowest bit: the two sweeps were the sort; signed / float keys are still mapped

@@ -258,6 +258,34 @@ def test_wide_key_hybrid_follows_the_range_of_the_keys(rs, torch, orc, t, bits, 
     c.close()
 
 
+@pytest.mark.parametrize("t", ["u64", "(u64,u64)"])
+def test_wide_key_hybrid_picks_its_workgroups_by_the_largest_buckets(rs, torch, orc, t):
+    """Keys with a triangular density (the sum of two uniform numbers): the buckets at the peak hold twice the average.
+    Which form of the bucket kernel runs -- 256, 512 or 1024 threads per bucket, or groups of small buckets, and of which
+    size -- is the device's choice from the counts (all are enqueued, each behind its gate): the smallest that holds all
+    but a handful of the buckets, so that no crowd of buckets goes through memory."""
+    d = _digits(rs, t)
+    es, ko, kb, _kind = util.TYPES[t]
+    lay = orc.Layout(*util.TYPES[t])
+    c = rs.Context(torch.cuda.current_device())
+    c.set_option(rs.OPT_WIDE_SORT, 3)
+    rng = np.random.default_rng(2024 + es)
+    idx_all = None
+    for n in (_mid_max(es) + 123457, 3 * _mid_max(es) + 11):
+        a = rng.integers(0, 1 << 62, size=n, dtype=np.uint64) + rng.integers(0, 1 << 62, size=n, dtype=np.uint64)
+        raw = np.zeros((n, es), dtype=np.uint8)
+        raw[:, ko:ko + kb] = a.view(np.uint8).reshape(n, 8)
+        idx = np.arange(n, dtype=np.uint64).view(np.uint8).reshape(n, 8)
+        for j, b in enumerate(b for b in range(es) if not ko <= b < ko + kb):
+            raw[:, b] = idx[:, j] if j < 8 else 0
+        x = torch.from_numpy(raw.reshape(-1).copy()).cuda()
+        rs.radix_sort(x, digits=d, ctx=c)
+        c.check()
+        assert (c.get_info(rs.INFO_LAST_PASSES) >> 24) & 15 == 5, (t, n)
+        assert np.array_equal(x.cpu().numpy(), orc.sort_parallel(raw.reshape(-1), lay, 8)), (t, n)
+    c.close()
+
+
 def test_wide_key_hybrid_decides_on_the_device(rs, torch, ctx, orc):
     """Default mode at a size where the hybrid is tried (2 GiB of u64): a uniform input takes it, a Zipf input is
     refused by the count (the LSD passes run, gated on the same verdict word), and after a refusal the context goes
