@@ -707,7 +707,8 @@ def test_atomic_ranks_cross_checked_under_load(rs, torch, orc):
 
 def test_options_reject_bad_values(rs, torch):
     c = rs.Context(torch.cuda.current_device())
-    for opt, bad in ((rs.OPT_TILE_SCHEDULE, 2), (rs.OPT_RANKING, 3), (rs.OPT_MAX_REGIONS, 33), (rs.OPT_HOT_LANES, 1), (99, 0)):
+    for opt, bad in ((rs.OPT_TILE_SCHEDULE, 2), (rs.OPT_RANKING, 3), (rs.OPT_MAX_REGIONS, 33), (rs.OPT_HOT_LANES, 1), (rs.OPT_MID_SORT, 4),
+                     (rs.OPT_WIDE_SORT, 4), (rs.OPT_BUCKET_SKIP, 2), (rs.OPT_BUCKET_GROUP, 2), (99, 0)):
         with pytest.raises(rs.RsxError):
             c.set_option(opt, bad)
     c.close()
