@@ -70,6 +70,16 @@ uint32_t bucket_cap_for(uint32_t es) {
         default: return bucket_cap(4);
     }
 }
+uint32_t wide_cap_for(uint32_t es) {  // what the hybrid's largest (1024-thread) workgroup holds
+    switch (es) {
+        case 8: return bucket_cape(8, wide_kpt_for(8), 1024);
+        case 12: return bucket_cape(12, wide_kpt_for(12), 1024);
+        case 16: return bucket_cape(16, wide_kpt_for(16), 1024);
+        case 24: return bucket_cape(24, wide_kpt_for(24), 1024);
+        case 32: return bucket_cape(32, wide_kpt_for(32), 1024);
+        default: return bucket_cape(4, wide_kpt_for(4), 1024);
+    }
+}
 uint64_t mid_max_for(uint32_t es) {
     switch (es) {
         case 2: return mid_max_elems(2);
@@ -364,7 +374,7 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
     if (ctx->wide_mode == 2) {
         wide = wide_type && n >= 65536;
     } else if (((ctx->wide_mode == 1 && n * (size_t)es >= wide_floor) || ctx->wide_mode == 3) && wide_size &&
-               (uint64_t)n / 65536u < (uint64_t)bucket_cap_for(es)) {  // (the real test is the device's, on the actual counts)
+               (uint64_t)n / 65536u < (uint64_t)wide_cap_for(es)) {  // (the real test is the device's, on the actual counts)
         // the last try's verdict (1 taken, 2 refused) counts for arrays like the one it was given on: same layout, n
         // within a factor of two (the multi-GPU drivers sort value ranges of slightly different lengths)
         volatile uint32_t* hint = reinterpret_cast<volatile uint32_t*>(ctx->host_err) + 9;
@@ -401,7 +411,7 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
         // else flat shares, and a count kernel of its own for that sweep
         size_t parts = n * (size_t)es / (32768 * sizeof(uint32_t));
         if (parts > (size_t)ctx->num_cu) parts = (size_t)ctx->num_cu;
-        static_assert(bucket_cap(8) < 0x8000u, "a bucket that fits LDS must not overflow a 16-bit counter");
+        static_assert(bucket_cape(8, wide_kpt_for(8), 1024) < 0x8000u && bucket_cape(4, wide_kpt_for(4), 1024) < 0x8000u, "a bucket that fits LDS must not overflow a 16-bit counter");
         uint32_t k = ctx->wide_mode == 2 ? 0u : (uint32_t)(parts / geom.num_regions);
         if (k > 0) parts = (size_t)k * geom.num_regions;
         rc = wideplan_dispatch(ctx, d_data, n, L, plan, st);
@@ -414,11 +424,11 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
             RSX_HIP(hipGetLastError());
             // which form of the bucket kernel runs is the device's choice too (launch_bucket16 enqueues them all):
             // groups of small buckets are on offer when the AVERAGE bucket is small (keys of at least 8 bytes)
-            const uint64_t cap1024 = bucket_cap_for(es), avg = (uint64_t)n / 65536u;
+            const uint64_t cap1024 = wide_big_form((int)es, n) ? wide_cap_for(es) : bucket_cap_for(es), cap512 = bucket_cap_for(es) / 2, avg = (uint64_t)n / 65536u;
             uint32_t gs = 0;
             if (D >= 8 && ctx->bucket_group)
-                while (gs < 6 && (avg << (gs + 1)) <= cap1024 / 2 * 3 / 4) ++gs;
-            hipLaunchKernelGGL(rsx_scan16_kernel, dim3(1), dim3(1024), 0, st, tot, starts, cap1024 / 4, cap1024 / 2, cap1024, gs >= 2 ? gs : 0u,
+                while (gs < 6 && (avg << (gs + 1)) <= cap512 * 3 / 4) ++gs;
+            hipLaunchKernelGGL(rsx_scan16_kernel, dim3(1), dim3(1024), 0, st, tot, starts, cap512 / 2, cap512, cap1024, gs >= 2 ? gs : 0u,
                                ctx->wide_mode == 2 ? 1u : 0u, plan, ctx->host_err_dev + 9);
             RSX_HIP(hipGetLastError());
         }

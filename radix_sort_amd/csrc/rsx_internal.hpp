@@ -217,6 +217,19 @@ struct LaunchTimer {
 // rsx_bucket_sort_kernel: 1024 threads x BKPT elements in registers, the bucket in LDS (<= 112 KiB, 8-byte elements
 // 136 KiB) beside 16 KiB of wave counters
 constexpr int bucket_kpt_for(int es) { return es <= 4 ? 28 : es == 8 ? 17 : es == 12 ? 9 : es == 16 ? 7 : es == 24 ? 4 : 3; }
+// ... and of the hybrid's 1024-thread form, which fills the LDS: as many registers as hold what 160 KiB leave beside the
+// wave counters (bucket_cape: 16-byte elements 9020 of 9216 slots); its smaller forms and the middle sizes keep the shorter
+// unrolled loops.
+constexpr int wide_kpt_for(int es) { return es <= 4 ? 28 : es == 8 ? 17 : es == 12 ? 12 : es == 16 ? 9 : es == 24 ? 6 : 5; }
+// whether an array's 1024-thread form is the longer one: when the average bucket is above 7/8 of what the shorter holds
+constexpr bool wide_big_form(int es, uint64_t n) { return n / 65536u > (uint64_t)1024 * (uint64_t)bucket_kpt_for(es) * 7u / 8u; }
+// elements a workgroup of `wg` threads x `kpt` registers holds in LDS (rsx_small_kernel.hpp cape<ES, KPT, WG>, same formula)
+constexpr uint32_t bucket_cape(int es, int kpt, int wg) {
+    const uint32_t slots = (uint32_t)wg * (uint32_t)kpt;
+    const uint32_t room = ((163840u - 1024u - (uint32_t)(wg / 64) * 256u * 4u - 64u - 3u * 256u * 4u) / (uint32_t)es) & ~3u;
+    return slots < room ? slots : room;
+}
+constexpr size_t bucket_cnt_bytes(int) { return 4; }
 // the hybrid's buffer (ctx->wide_buf): bucket totals [65536], block totals [256], starts [65537] (u64), then its WidePlan
 constexpr size_t WIDE_PLAN_OFFSET = (65536 + 256 + 65537 + 1) * sizeof(uint64_t);
 constexpr uint32_t bucket_cap(int es) { return 1024u * (uint32_t)bucket_kpt_for(es); }

@@ -351,10 +351,10 @@ int launch_bucket_sort(rsx_ctx* ctx, const void* src, void* dst, const RegionGeo
         set_skip_mask(ctx, a, L);
         LaunchTimer lt(ctx, RSX_PROF_OTHER, st);
         if (ctx->bucket_small) {  // small buckets, all known to fit: 256 threads each
-            const size_t lds = (size_t)256 * KPT * ES + 4 * RADIX * sizeof(uint32_t) + 64 + 3 * RADIX * sizeof(uint32_t);
+            const size_t lds = (size_t)cape<ES, KPT, 256>() * ES + 4 * RADIX * bucket_cnt_bytes(ES) + 64 + 3 * RADIX * sizeof(uint32_t);
             hipLaunchKernelGGL((rsx_bucket_sort_kernel<ES, KPT, 256>), dim3(RADIX), dim3(256), lds, st, a);
         } else {
-            const size_t lds = (size_t)1024 * KPT * ES + 16 * RADIX * sizeof(uint32_t) + 64 + 3 * RADIX * sizeof(uint32_t);
+            const size_t lds = (size_t)cape<ES, KPT, 1024>() * ES + 16 * RADIX * bucket_cnt_bytes(ES) + 64 + 3 * RADIX * sizeof(uint32_t);
             auto kern = rsx_bucket_sort_kernel<ES, KPT, 1024>;
             static thread_local bool attr_set = false;
             if (!attr_set) {  // more than 64 KiB of dynamic LDS has to be asked for
@@ -471,13 +471,15 @@ int launch_bucket16(rsx_ctx* ctx, void* data, void* scratch, size_t n, const rsx
         const uint64_t avg = (uint64_t)n / 65536u;
         const uint32_t gs = bucket16_group_shift<ES>(ctx, n, L);
         const Gate base = ctx->gate;  // (null word: no gates -- never the case for this kernel)
-        auto go = [&](auto wgc, uint32_t form, uint32_t group_shift) {
+        auto go = [&](auto wgc, auto kc, uint32_t form, uint32_t group_shift) {
             constexpr int WGS = decltype(wgc)::value;
+            constexpr int K = decltype(kc)::value;
             SmallArgs b = a;
             b.group_shift = group_shift;
             if (group_shift) b.passes = L->key_bytes;
-            const size_t lds = (size_t)WGS * KPT * ES + (WGS / 64) * RADIX * sizeof(uint32_t) + 64 + 3 * RADIX * sizeof(uint32_t);
-            auto kern = rsx_bucket16_kernel<ES, KPT, WGS>;
+            static_assert(cape<ES, K, WGS>() == bucket_cape(ES, K, WGS), "host and device agree on what a workgroup holds");
+            const size_t lds = (size_t)cape<ES, K, WGS>() * ES + (WGS / 64) * RADIX * bucket_cnt_bytes(ES) + 64 + 3 * RADIX * sizeof(uint32_t);
+            auto kern = rsx_bucket16_kernel<ES, K, WGS>;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             int per_cu = (int)((size_t)163840 / lds);
             if (per_cu < 1) per_cu = 1;
@@ -485,10 +487,13 @@ int launch_bucket16(rsx_ctx* ctx, void* data, void* scratch, size_t n, const rsx
             const Gate g{base.word, VERDICT_PATH_MASK | VERDICT_FORM_MASK, VERDICT_HYBRID | form};
             hipLaunchKernelGGL(kern, dim3((uint32_t)(ctx->num_cu * per_cu)), dim3(WGS), lds, st, b, starts, scratch, plan, g);
         };
-        if (gs >= 2) go(std::integral_constant<int, 512>{}, VERDICT_GROUPS, gs);
-        if (avg <= (uint64_t)256 * KPT) go(std::integral_constant<int, 256>{}, VERDICT_WG256, 0);
-        if (avg <= (uint64_t)512 * KPT) go(std::integral_constant<int, 512>{}, VERDICT_WG512, 0);
-        go(std::integral_constant<int, 1024>{}, VERDICT_WG1024, 0);
+        using std::integral_constant;
+        constexpr int KBIG = wide_kpt_for(ES);  // (the longer form only where the average bucket needs it: wide_big_form)
+        if (gs >= 2) go(integral_constant<int, 512>{}, integral_constant<int, KPT>{}, VERDICT_GROUPS, gs);
+        if (avg <= (uint64_t)256 * KPT) go(integral_constant<int, 256>{}, integral_constant<int, KPT>{}, VERDICT_WG256, 0);
+        if (avg <= (uint64_t)512 * KPT) go(integral_constant<int, 512>{}, integral_constant<int, KPT>{}, VERDICT_WG512, 0);
+        if (KBIG != KPT && wide_big_form(ES, n)) go(integral_constant<int, 1024>{}, integral_constant<int, KBIG>{}, VERDICT_WG1024, 0);
+        else go(integral_constant<int, 1024>{}, integral_constant<int, KPT>{}, VERDICT_WG1024, 0);
         RSX_HIP(hipGetLastError());
         return RSX_OK;
     }

@@ -53,6 +53,36 @@ struct PassPlan {
     uint32_t mask[8];
 };
 
+// The per-wave digit counters of these sorts.  (16-bit halves, two to a word, for elements of 12 bytes and more would
+// save 8 KiB of LDS per 1024 threads -- measured: lanes on digits 2k and 2k+1 then meet on one word, and with the extra
+// shifts every size of 16-byte elements ran 8-20 % slower.  Kept as a switch; off.)
+template <int ES>
+struct WaveCnt {
+    static constexpr bool HALF = false;
+    using T = typename std::conditional<HALF, uint16_t, uint32_t>::type;
+    static __device__ __forceinline__ void zero(T* my, uint32_t lane) {
+        uint32_t* w = reinterpret_cast<uint32_t*>(my);
+#pragma unroll
+        for (int i = 0; i < (HALF ? 2 : 4); ++i) w[i * WAVE + lane] = 0;
+    }
+    static __device__ __forceinline__ uint32_t add_rtn(T* my, uint32_t d, uint32_t v) {  // returns the count before
+        if constexpr (HALF) {
+            const uint32_t sh = (d & 1u) * 16u;
+            return (atomicAdd(reinterpret_cast<uint32_t*>(my) + (d >> 1), v << sh) >> sh) & 0xFFFFu;
+        } else {
+            return atomicAdd(&my[d], v);
+        }
+    }
+};
+// What a workgroup of WG threads x KPT registers holds in LDS: WG * KPT elements, or what 160 KiB leave beside the wave
+// counters and the 3 KiB of the sort through memory (1024 threads of 16-byte elements: 9020 of 9216 slots).
+template <int ES, int KPT, int WG>
+__host__ __device__ constexpr uint32_t cape() {
+    constexpr uint32_t slots = (uint32_t)WG * KPT;
+    constexpr uint32_t room = ((163840u - 1024u - (uint32_t)(WG / WAVE) * RADIX * (uint32_t)sizeof(typename WaveCnt<ES>::T) - 64u - 3u * RADIX * 4u) / (uint32_t)ES) & ~3u;  // (1 KiB for the kernels' static LDS)
+    return slots < room ? slots : room;
+}
+
 // The elements of a workgroup's array [0, n) as its threads hold them: wave w holds [w*64*kp, (w+1)*64*kp), round j at
 // +j*64 -- (wave, round, lane) order == index order, so ranks are stable.  kp = ceil(n / WG) rounds are in use.
 template <int ES, int KPT, int WG>
@@ -81,16 +111,16 @@ __device__ __forceinline__ void local_passes(const SmallArgs& a, Elem<ES> (&e)[K
     constexpr int NWAVE = WG / WAVE;
     using E = Elem<ES>;
     E* s_elems = reinterpret_cast<E*>(smem);                                              // [WG * KPT]
-    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem + (size_t)WG * KPT * sizeof(E));  // [NWAVE][256]
-    uint32_t* s_misc = s_cnt + NWAVE * RADIX;                                             // [NWAVE]
+    using C = WaveCnt<ES>;
+    typename C::T* s_cnt = reinterpret_cast<typename C::T*>(smem + (size_t)cape<ES, KPT, WG>() * sizeof(E));  // [NWAVE][256]
+    uint32_t* s_misc = reinterpret_cast<uint32_t*>(s_cnt + NWAVE * RADIX);                         // [NWAVE]
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t kp = (n + WG - 1) / WG;          // rounds in use, 1..KPT (wave-uniform, the same for all)
     const uint32_t seg = wave * (WAVE * kp) + lane;
-    uint32_t* my = s_cnt + wave * RADIX;
+    typename C::T* my = s_cnt + wave * RADIX;
     for (uint32_t pass = first; pass < stop; ++pass) {
         const DigitSpec spec = a.spec[pass];
-#pragma unroll
-        for (int i = 0; i < RADIX / WAVE; ++i) my[i * WAVE + lane] = 0;
+        C::zero(my, lane);
         // the slots past n are padding: digit 255, and being the highest indices they rank behind every real 255
         auto digit_of = [&](int j) -> uint32_t {
             return (seg + (uint32_t)j * WAVE >= n) ? 255u : elem_digit<ES, false>(e[j], spec);
@@ -102,12 +132,12 @@ __device__ __forceinline__ void local_passes(const SmallArgs& a, Elem<ES> (&e)[K
             if ((uint32_t)j < kp) {
                 const uint32_t d = digit_of(j);
                 if (a.rank_atomic) {  // lanes of one instruction on one address are applied in lane order (rsx_lds_order_kernel)
-                    rk[j] = atomicAdd(&my[d], 1u);
+                    rk[j] = C::add_rtn(my, d, 1u);
                 } else {
                     const uint64_t m = match_digit(d);
                     const uint32_t below = mbcnt64(m);
                     const uint32_t seen = my[d];
-                    if (below == 0) atomicAdd(&my[d], (uint32_t)__popcll(m));
+                    if (below == 0) (void)C::add_rtn(my, d, (uint32_t)__popcll(m));
                     rk[j] = seen + below;
                 }
             }
@@ -128,14 +158,21 @@ __device__ __forceinline__ void local_passes(const SmallArgs& a, Elem<ES> (&e)[K
 #pragma unroll
             for (int w = 0; w < NWAVE; ++w) {
                 const uint32_t c = s_cnt[w * RADIX + tid];
-                s_cnt[w * RADIX + tid] = run;
+                s_cnt[w * RADIX + tid] = (typename C::T)run;
                 run += c;
             }
         }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < KPT; ++j)
-            if ((uint32_t)j < kp) s_elems[my[digit_of(j)] + rk[j]] = e[j];
+            if ((uint32_t)j < kp) {
+                // (padding slots, digit 255, rank last and land past n: inside LDS only if it has all WG * KPT slots)
+                if constexpr (cape<ES, KPT, WG>() < (uint32_t)WG * KPT) {
+                    if (seg + (uint32_t)j * WAVE < n) s_elems[(uint32_t)my[digit_of(j)] + rk[j]] = e[j];
+                } else {
+                    s_elems[(uint32_t)my[digit_of(j)] + rk[j]] = e[j];
+                }
+            }
         __syncthreads();
         if (pass + 1 < stop) {
 #pragma unroll
@@ -175,16 +212,17 @@ __device__ __forceinline__ void local_sort(const SmallArgs& a, const Elem<ES>* _
 template <int ES, int KPT, int WG>
 __device__ void big_bucket_sort(const SmallArgs& a, Elem<ES>* buf0, Elem<ES>* buf1, const uint32_t m, unsigned char* smem) {
     constexpr int NWAVE = WG / WAVE;
-    constexpr uint32_t CH = (uint32_t)WG * KPT;
+    constexpr uint32_t CH = cape<ES, KPT, WG>();
     using E = Elem<ES>;
     E* s_elems = reinterpret_cast<E*>(smem);
-    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem + (size_t)WG * KPT * sizeof(E));
-    uint32_t* s_misc = s_cnt + NWAVE * RADIX;  // [NWAVE]
+    using C = WaveCnt<ES>;
+    typename C::T* s_cnt = reinterpret_cast<typename C::T*>(smem + (size_t)cape<ES, KPT, WG>() * sizeof(E));
+    uint32_t* s_misc = reinterpret_cast<uint32_t*>(s_cnt + NWAVE * RADIX);  // [NWAVE]
     uint32_t* s_gbase = s_misc + NWAVE;        // [256] where the next element of each digit goes, relative to the bucket
     uint32_t* s_dstart = s_gbase + RADIX;      // [256] start of each digit's run in the sorted chunk
     uint32_t* s_dcount = s_dstart + RADIX;     // [256] its length
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint32_t* my = s_cnt + wave * RADIX;
+    typename C::T* my = s_cnt + wave * RADIX;
     E* src = buf0;
     E* dst = buf1;
     for (uint32_t pass = 0; pass < a.passes; ++pass) {
@@ -220,8 +258,7 @@ __device__ void big_bucket_sort(const SmallArgs& a, Elem<ES>* buf0, Elem<ES>* bu
                     if (p < n) e[j] = src[c0 + p];
                 }
             }
-#pragma unroll
-            for (int i = 0; i < RADIX / WAVE; ++i) my[i * WAVE + lane] = 0;
+            C::zero(my, lane);
             auto digit_of = [&](int j) -> uint32_t {
                 return (seg + (uint32_t)j * WAVE >= n) ? 255u : elem_digit<ES, false>(e[j], spec);
             };
@@ -234,7 +271,7 @@ __device__ void big_bucket_sort(const SmallArgs& a, Elem<ES>* buf0, Elem<ES>* bu
                     const uint64_t mm = match_digit(d);  // (ballots: the rare path does not depend on the LDS ordering self-test)
                     const uint32_t below = mbcnt64(mm);
                     const uint32_t seen = my[d];
-                    if (below == 0) atomicAdd(&my[d], (uint32_t)__popcll(mm));
+                    if (below == 0) (void)C::add_rtn(my, d, (uint32_t)__popcll(mm));
                     rk[j] = seen + below;
                 }
             }
@@ -255,14 +292,21 @@ __device__ void big_bucket_sort(const SmallArgs& a, Elem<ES>* buf0, Elem<ES>* bu
 #pragma unroll
                 for (int w = 0; w < NWAVE; ++w) {
                     const uint32_t c = s_cnt[w * RADIX + tid];
-                    s_cnt[w * RADIX + tid] = run;
+                    s_cnt[w * RADIX + tid] = (typename C::T)run;
                     run += c;
                 }
             }
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < KPT; ++j)
-                if ((uint32_t)j < kp) s_elems[my[digit_of(j)] + rk[j]] = e[j];
+                if ((uint32_t)j < kp) {
+                    // (padding slots, digit 255, rank last and land past n: inside LDS only if it has all WG * KPT slots)
+                    if constexpr (cape<ES, KPT, WG>() < (uint32_t)WG * KPT) {
+                        if (seg + (uint32_t)j * WAVE < n) s_elems[(uint32_t)my[digit_of(j)] + rk[j]] = e[j];
+                    } else {
+                        s_elems[(uint32_t)my[digit_of(j)] + rk[j]] = e[j];
+                    }
+                }
             __syncthreads();
             for (uint32_t i = tid; i < n; i += WG) {
                 E x = s_elems[i];
@@ -460,7 +504,7 @@ __global__ __launch_bounds__(WG) void rsx_bucket_sort_kernel(const SmallArgs a) 
     }
     __syncthreads();  // smem is the sort's from here
     if (count == 0) return;
-    if (count > (uint64_t)WG * KPT) {  // a skewed top digit the host did not foresee: through memory, by this workgroup alone
+    if (count > (uint64_t)cape<ES, KPT, WG>()) {  // a skewed top digit the host did not foresee: through memory, by this workgroup alone
         big_bucket_sort<ES, KPT, WG>(a, const_cast<Elem<ES>*>(static_cast<const Elem<ES>*>(a.src)) + start,
                                      static_cast<Elem<ES>*>(a.data) + start, (uint32_t)count, smem);
         return;
@@ -474,7 +518,7 @@ __global__ __launch_bounds__(WG) void rsx_bucket_sort_kernel(const SmallArgs a) 
         pp.first = (a.passes > a.keep && !a.no_skip) ? a.passes - a.keep : 0;
 #pragma unroll
         for (int w = 0; w < 8; ++w) pp.mask[w] = a.cmp_mask[w];
-        uint32_t* s_flag = reinterpret_cast<uint32_t*>(smem + (size_t)WG * KPT * sizeof(Elem<ES>)) + (WG / WAVE) * RADIX + (WG / WAVE);
+        uint32_t* s_flag = reinterpret_cast<uint32_t*>(reinterpret_cast<typename WaveCnt<ES>::T*>(smem + (size_t)cape<ES, KPT, WG>() * sizeof(Elem<ES>)) + (WG / WAVE) * RADIX) + (WG / WAVE);
         local_sort_skip<ES, KPT, WG>(a, static_cast<const Elem<ES>*>(a.src) + start, static_cast<Elem<ES>*>(a.data) + start, (uint32_t)count, smem, pp,
                                      s_flag);
     }
@@ -487,7 +531,7 @@ __global__ __launch_bounds__(WG, RSX_B16_WAVES(WG)) void rsx_bucket16_kernel(con
     if (!gate_open(gate)) return;
     using E = Elem<ES>;
     constexpr int NWAVE = WG / WAVE;
-    uint32_t* s_flag = reinterpret_cast<uint32_t*>(smem + (size_t)WG * KPT * sizeof(E)) + NWAVE * RADIX + NWAVE;  // (s_misc is [NWAVE]; 16 words there)
+    uint32_t* s_flag = reinterpret_cast<uint32_t*>(reinterpret_cast<typename WaveCnt<ES>::T*>(smem + (size_t)cape<ES, KPT, WG>() * sizeof(E)) + NWAVE * RADIX) + NWAVE;  // (s_misc is [NWAVE]; 16 words there)
     // A bucket of m elements that agree on their window (and everything above it) is, as a rule, told apart by the next
     // 2 log2(m) bits or so: the passes start at the digit that leaves four -- five if the top one reaches into the
     // window -- (32+ bits for at most 2^15 elements), the neighbours that still agree afterwards are put right one run
@@ -531,7 +575,7 @@ __global__ __launch_bounds__(WG, RSX_B16_WAVES(WG)) void rsx_bucket16_kernel(con
         const uint64_t gstart = starts[b0];
         const uint64_t gcount = starts[b0 + (1u << gs)] - gstart;  // (the same for every thread: uniform control flow below)
         if (gcount == 0) continue;
-        const bool whole = gs == 0 || gcount <= (uint64_t)WG * KPT;
+        const bool whole = gs == 0 || gcount <= (uint64_t)cape<ES, KPT, WG>();
         const uint32_t nsub = whole ? 1u : 1u << gs;
         for (uint32_t sub = 0; sub < nsub; ++sub) {  // (one call site each for the LDS sort and the sort through memory)
             uint64_t start = gstart, count = gcount;
@@ -541,7 +585,7 @@ __global__ __launch_bounds__(WG, RSX_B16_WAVES(WG)) void rsx_bucket16_kernel(con
             }
             if (count != 0) {
                 E* bucket = static_cast<E*>(a.data) + start;
-                if (count <= (uint64_t)WG * KPT) {
+                if (count <= (uint64_t)cape<ES, KPT, WG>()) {
                     const uint32_t first = pp.first;
                     if (!whole) pp.first = 0;
                     local_sort_skip<ES, KPT, WG>(a, bucket, bucket, (uint32_t)count, smem, pp, s_flag);
