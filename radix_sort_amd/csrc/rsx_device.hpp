@@ -314,6 +314,9 @@ struct WidePlan {
     DigitSpec specs[3];   // [0] low, [1] high digit of the window (plain digits of the MAPPED key); [2] filler (sweeps read pairs)
     uint32_t ref[8];      // the mapped first element
     uint32_t himask[8];   // key bits above the window, per element dword
+    uint32_t scan_cnt[8]; // rsx_scan16_kernel's workgroups add up here: [0..2] buckets above what 256 / 512 / 1024 threads hold,
+                          // [3..7] groups of 2^(g) buckets, g = 2 .. 6, above what 512 hold; [scan_done] how many have (zeroed by the plan kernel)
+    uint32_t scan_done;
 };
 
 // --------------------------------------------------------------- histogram --

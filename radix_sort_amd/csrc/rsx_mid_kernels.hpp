@@ -215,19 +215,22 @@ __global__ __launch_bounds__(1024) void rsx_wideplan_kernel(const Elem<ES>* __re
     }
     __syncthreads();
     if (tid != 0) return;
-    uint32_t diff[NW];
-    for (int w = 0; w < NW; ++w) {
-        diff[w] = 0;
-        for (int q = 0; q < 16; ++q) diff[w] |= s_or[q][w];
-    }
-    // highest differing KEY bit (key bit i is element bit 8 * key_offset + i)
+    // highest differing KEY bit (key bit i is element bit 8 * key_offset + i); all indices static: registers, no scratch
+    const uint32_t key_lo = 8u * key_offset, key_hi = 8u * (key_offset + key_bytes) - 1u;  // element bits of the key, inclusive
+    auto bits_of = [](uint32_t w, uint32_t from, uint32_t to) -> uint32_t {  // bits of dword w whose element bit index is in [from, to]
+        const uint32_t lo = from > 32u * w ? from : 32u * w, hi = to < 32u * w + 31u ? to : 32u * w + 31u;
+        if (lo > hi) return 0u;
+        const uint32_t width = hi - lo + 1u;
+        return (width == 32u ? ~0u : ((1u << width) - 1u)) << (lo - 32u * w);
+    };
     int t = -1;
-    for (int bit = (int)key_bytes * 8 - 1; bit >= 0; --bit) {
-        const uint32_t eb = 8u * key_offset + (uint32_t)bit;
-        if ((diff[eb >> 5] >> (eb & 31u)) & 1u) {
-            t = bit;
-            break;
-        }
+#pragma unroll
+    for (int w = NW - 1; w >= 0; --w) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v |= s_or[q][w];
+        v &= bits_of((uint32_t)w, key_lo, key_hi);
+        if (t < 0 && v != 0u) t = (int)(32u * (uint32_t)w + 31u - (uint32_t)__builtin_clz(v)) - (int)key_lo;
     }
     uint32_t violation = t < 0 ? 1u : 0u;  // every sampled key the same: nothing to place a window by
     const int top = t < 15 ? 15 : t;
@@ -256,14 +259,12 @@ __global__ __launch_bounds__(1024) void rsx_wideplan_kernel(const Elem<ES>* __re
     plan->group_keep = (group_end * 8u - 1u - (uint32_t)top) != 0u ? 6u : 5u;
     plan->window_top = (uint32_t)top;
     plan->violation = violation;
+    for (int i = 0; i < 8; ++i) plan->scan_cnt[i] = 0;
+    plan->scan_done = 0;
+#pragma unroll
     for (int w = 0; w < 8; ++w) {
-        plan->ref[w] = w < NW ? first.w[w] : 0u;
-        uint32_t m = 0;
-        for (uint32_t b = 0; b < 32; ++b) {
-            const int keybit = (int)(32u * (uint32_t)w + b) - (int)(8u * key_offset);
-            if (keybit > top && keybit <= last) m |= 1u << b;
-        }
-        plan->himask[w] = m;
+        plan->ref[w] = w < NW ? first.w[w < NW ? w : 0] : 0u;
+        plan->himask[w] = top < last ? bits_of((uint32_t)w, key_lo + (uint32_t)top + 1u, key_hi) : 0u;  // key bits above the window
     }
 }
 

@@ -214,92 +214,82 @@ __global__ __launch_bounds__(256) void rsx_total16_kernel(const uint32_t* __rest
     if (tid == 0) BT[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
-// Exclusive scan of the 65536 bin totals (one workgroup: 64 bins per thread) -> starts[65537]; *verdict = 1 if no bin
-// exceeds `cap`, else 2 (wide keys: whether every 16-bit bucket fits a workgroup's LDS).
-__global__ __launch_bounds__(1024) void rsx_scan16_kernel(const uint64_t* __restrict__ tot, uint64_t* __restrict__ starts, uint64_t cap256,
-                                                          uint64_t cap512, uint64_t cap1024, uint32_t gs_max, uint32_t forced,
-                                                          WidePlan* __restrict__ plan, uint32_t* __restrict__ host_verdict) {
-    __shared__ uint64_t ws[16];
-    __shared__ uint32_t wover[16][3 + 8];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    uint64_t mine = 0;
-    uint32_t o256 = 0, o512 = 0, o1024 = 0;  // buckets above what a workgroup of 256 / 512 / 1024 threads holds
-    uint32_t og[7] = {0, 0, 0, 0, 0, 0, 0};  // og[g]: groups of 2^g consecutive buckets above what 512 threads hold (g <= 6: inside my 64 bins)
-    uint64_t gsum[7] = {0, 0, 0, 0, 0, 0, 0};
-    for (int k = 0; k < 64; ++k) {
-        const uint64_t c = tot[(size_t)tid * 64 + k];
-        mine += c;
-        o256 += c > cap256 ? 1u : 0u;
-        o512 += c > cap512 ? 1u : 0u;
-        o1024 += c > cap1024 ? 1u : 0u;
+// Exclusive scan of the 65536 bin totals -> starts[65537], and the verdict of the wide-key hybrid.  grid = 256 workgroups
+// of 256 threads: workgroup b scans bins [256 b, 256 b + 256) from the block totals BT (rsx_total16_kernel) of the blocks
+// before it; all add what they see to WidePlan::scan_cnt -- buckets above what a workgroup of 256 / 512 / 1024 threads
+// holds, groups of 2^g consecutive buckets (g = 2 .. 6, from the butterfly over a wave's 64 bins) above what 512 hold --
+// and the last one to finish decides.  (As ONE workgroup this took 49-76 us in three forms: a single CU moves its 1.5 MB
+// no faster; 12 % of a 2^23-key sort.)
+__global__ __launch_bounds__(256) void rsx_scan16_kernel(const uint64_t* __restrict__ tot, const uint64_t* __restrict__ BT,
+                                                         uint64_t* __restrict__ starts, uint64_t cap256, uint64_t cap512, uint64_t cap1024,
+                                                         uint32_t gs_max, uint32_t forced, WidePlan* __restrict__ plan,
+                                                         uint32_t* __restrict__ host_verdict) {
+    __shared__ uint64_t ws[4], wb[4];
+    __shared__ uint32_t s_last;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, b = blockIdx.x;
+    const uint64_t c = tot[(size_t)b * 256u + tid];
+    uint64_t before = tid < b ? BT[tid] : 0ull;  // blocks before mine
 #pragma unroll
-        for (int g = 2; g <= 6; ++g) {
-            gsum[g] += c;
-            if (((k + 1) & ((1 << g) - 1)) == 0) {
-                og[g] += gsum[g] > cap512 ? 1u : 0u;
-                gsum[g] = 0;
-            }
-        }
-    }
-    uint64_t x = mine;
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+    uint64_t x = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const uint64_t y = __shfl_up(x, o);
         if (lane >= (uint32_t)o) x += y;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        o256 += __shfl_xor(o256, o);
-        o512 += __shfl_xor(o512, o);
-        o1024 += __shfl_xor(o1024, o);
-#pragma unroll
-        for (int g = 2; g <= 6; ++g) og[g] += __shfl_xor(og[g], o);
-    }
     if (lane == 63) ws[wave] = x;
-    if (lane == 0) {
-        wover[wave][0] = o256;
-        wover[wave][1] = o512;
-        wover[wave][2] = o1024;
+    if (lane == 0) wb[wave] = before;
+    // what this wave's 64 bins add to the counts
+    const uint32_t o256 = (uint32_t)__popcll(__ballot(c > cap256)), o512 = (uint32_t)__popcll(__ballot(c > cap512)),
+                   o1024 = (uint32_t)__popcll(__ballot(c > cap1024));
+    uint32_t og[7] = {0, 0, 0, 0, 0, 0, 0};
+    uint64_t sum = c;
 #pragma unroll
-        for (int g = 2; g <= 6; ++g) wover[wave][3 + g] = og[g];
+    for (int g = 1; g <= 6; ++g) {
+        sum += __shfl_xor(sum, 1 << (g - 1));  // every lane: the sum of its aligned group of 2^g bins
+        if (g >= 2) og[g] = (uint32_t)__popcll(__ballot((lane & ((1u << g) - 1u)) == 0u && sum > cap512));
+    }
+    if (lane == 0) {
+        if (o256) atomicAdd(&plan->scan_cnt[0], o256);
+        if (o512) atomicAdd(&plan->scan_cnt[1], o512);
+        if (o1024) atomicAdd(&plan->scan_cnt[2], o1024);
+#pragma unroll
+        for (int g = 2; g <= 6; ++g)
+            if (og[g]) atomicAdd(&plan->scan_cnt[1 + g], og[g]);
     }
     __syncthreads();
-    uint64_t run = x - mine;
+    uint64_t run = wb[0] + wb[1] + wb[2] + wb[3] + x - c;
     for (uint32_t w = 0; w < wave; ++w) run += ws[w];
-    for (int k = 0; k < 64; ++k) {
-        starts[(size_t)tid * 64 + k] = run;
-        run += tot[(size_t)tid * 64 + k];
-    }
-    if (tid == 1023) starts[65536] = run;
-    if (tid == 0) {
-        uint32_t n256 = 0, n512 = 0, n1024 = 0;
-        for (int w = 0; w < 16; ++w) {
-            n256 += wover[w][0];
-            n512 += wover[w][1];
-            n1024 += wover[w][2];
-        }
-        // The smallest workgroup that holds all but a handful of the buckets (those few go through memory, one workgroup
-        // each: tolerable for buckets of its own size class, not for what exceeds the largest workgroup -- then the LSD
-        // passes run, unless the hybrid is forced).  Small buckets in groups if the host's average says so and no bucket
-        // is larger than a group's workgroup: the largest group size (up to the host's) whose groups fit.
-        constexpr uint32_t FEW = 8;
-        const uint32_t violation = __hip_atomic_load(&plan->violation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (set by an earlier kernel of the stream)
-        uint32_t gshift = 0;  // the largest group size on offer whose groups (all but a handful) fit their workgroup
-        for (uint32_t g = gs_max <= 6u ? gs_max : 6u; g >= 2u && gshift == 0u; --g) {
-            uint32_t over = 0;
-            for (int w = 0; w < 16; ++w) over += wover[w][3 + g];
-            if (over <= FEW) gshift = g;
-        }
-        plan->group_shift = gshift;
-        uint32_t v;
-        if (violation != 0 || (n1024 != 0 && !forced)) v = VERDICT_LSD;
-        else if (gshift != 0 && n512 == 0) v = VERDICT_HYBRID | VERDICT_GROUPS;
-        else if (n256 <= FEW) v = VERDICT_HYBRID | VERDICT_WG256;
-        else if (n512 <= FEW) v = VERDICT_HYBRID | VERDICT_WG512;
-        else v = VERDICT_HYBRID | VERDICT_WG1024;
-        plan->verdict = v;
-        __hip_atomic_store(host_verdict, (v & VERDICT_HYBRID) ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // the host's forecast for later sorts
-    }
+    starts[(size_t)b * 256u + tid] = run;
+    if (b == gridDim.x - 1 && tid == 255) starts[65536] = run + c;
+    // the last workgroup to get here decides
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&plan->scan_done, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (s_last == 0 || tid != 0) return;
+    __threadfence();
+    uint32_t cnt[8];
+    for (int i = 0; i < 8; ++i) cnt[i] = __hip_atomic_load(&plan->scan_cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t n256 = cnt[0], n512 = cnt[1], n1024 = cnt[2];
+    // The smallest workgroup that holds all but a handful of the buckets (those few go through memory, one workgroup
+    // each: tolerable for buckets of its own size class, not for what exceeds the largest workgroup -- then the LSD
+    // passes run, unless the hybrid is forced).  Small buckets in groups if the host's average says so and no bucket
+    // is larger than a group's workgroup: the largest group size (up to the host's) whose groups fit.
+    constexpr uint32_t FEW = 8;
+    const uint32_t violation = __hip_atomic_load(&plan->violation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (set by an earlier kernel of the stream)
+    uint32_t gshift = 0;
+    for (uint32_t g = gs_max <= 6u ? gs_max : 6u; g >= 2u && gshift == 0u; --g)
+        if (cnt[1 + g] <= FEW) gshift = g;
+    plan->group_shift = gshift;
+    uint32_t v;
+    if (violation != 0 || (n1024 != 0 && !forced)) v = VERDICT_LSD;
+    else if (gshift != 0 && n512 == 0) v = VERDICT_HYBRID | VERDICT_GROUPS;
+    else if (n256 <= FEW) v = VERDICT_HYBRID | VERDICT_WG256;
+    else if (n512 <= FEW) v = VERDICT_HYBRID | VERDICT_WG512;
+    else v = VERDICT_HYBRID | VERDICT_WG1024;
+    plan->verdict = v;
+    __hip_atomic_store(host_verdict, (v & VERDICT_HYBRID) ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // the host's forecast for later sorts
 }
 
 // Writes the runs.  The output is cut into 1 KiB steps (64 lanes x 8 elements); a wave takes every 4th step of its
