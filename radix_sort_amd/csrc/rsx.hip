@@ -334,11 +334,7 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
         uint64_t* tot = reinterpret_cast<uint64_t*>(static_cast<char*>(d_tmp) + parts * 32768 * sizeof(uint32_t));
         uint64_t* BT = tot + 65536;
         const uint32_t xor_mask = L->key_kind == RSX_KEY_SIGNED ? 0x8000u : 0u;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rsx_count16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-            attr_set = true;
-        }
+        ensure_lds(ctx, reinterpret_cast<const void*>(rsx_count16_kernel), 131072);
         {
             LaunchTimer lt(ctx, RSX_PROF_HIST, st);
             hipLaunchKernelGGL(rsx_count16_kernel, dim3((uint32_t)parts), dim3(1024), 131072, st, static_cast<const uint16_t*>(d_data),

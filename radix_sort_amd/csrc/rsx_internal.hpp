@@ -87,6 +87,7 @@ struct rsx_ctx {
     uint32_t wide_skip = 0;     // sorts to go without trying the wide-key hybrid (the last try was refused on the device)
     char* wide_buf = nullptr;   // wide-key hybrid: bin totals [65536] u64, bin-block sums [256] u64, bucket starts [65537] u64, verdict u32
     uint32_t wide_mode = 1;     // RSX_OPT_WIDE_SORT: 0 off, 1 auto, 2 always, 3 auto without the size floor
+    std::vector<const void*> lds_attr;  // kernels whose dynamic-LDS limit was raised on this context's device (ensure_lds)
     const rsx::DigitSpec* spec_dev = nullptr;  // the hybrid's sweeps read their digits from the device's plan (WidePlan::specs)
     uint64_t wide_tried_sig = 0, wide_refused_sig = 0;  // (layout, n) of the last hybrid try / of the last refusal
     uint32_t bucket_no_skip = 0;  // RSX_OPT_BUCKET_SKIP == 0
@@ -280,6 +281,14 @@ inline uint64_t status_rows(const RegionGeom& g, uint32_t es) {
 }
 // chain prefixes are relative to the region: 30 value bits suffice up to 2^30-element regions
 inline bool status32(const RegionGeom& g) { return g.region_shift <= 30; }
+
+// More than 64 KiB of dynamic LDS has to be asked for, per kernel and per DEVICE: once per context.
+inline void ensure_lds(rsx_ctx* ctx, const void* kernel, size_t bytes) {
+    for (const void* k : ctx->lds_attr)
+        if (k == kernel) return;
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    ctx->lds_attr.push_back(kernel);
+}
 
 inline DigitSpec make_spec(const rsx_layout* L, uint32_t digit) {
     DigitSpec s;

@@ -356,11 +356,7 @@ int launch_bucket_sort(rsx_ctx* ctx, const void* src, void* dst, const RegionGeo
         } else {
             const size_t lds = (size_t)cape<ES, KPT, 1024>() * ES + 16 * RADIX * bucket_cnt_bytes(ES) + 64 + 3 * RADIX * sizeof(uint32_t);
             auto kern = rsx_bucket_sort_kernel<ES, KPT, 1024>;
-            static thread_local bool attr_set = false;
-            if (!attr_set) {  // more than 64 KiB of dynamic LDS has to be asked for
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                attr_set = true;
-            }
+            ensure_lds(ctx, reinterpret_cast<const void*>(kern), lds);
             hipLaunchKernelGGL(kern, dim3(RADIX), dim3(1024), lds, st, a);
         }
         RSX_HIP(hipGetLastError());
@@ -396,12 +392,12 @@ int launch_count16top(rsx_ctx* ctx, const void* src, size_t n, const rsx_layout*
         LaunchTimer lt(ctx, RSX_PROF_HIST, st);
         if (L->key_kind != RSX_KEY_UNSIGNED) {
             auto kern = rsx_count16top_kernel<ES, true>;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            ensure_lds(ctx, reinterpret_cast<const void*>(kern), 131072);
             hipLaunchKernelGGL(kern, dim3(parts), dim3(1024), 131072, st, static_cast<const Elem<ES>*>(src), (uint64_t)n, plan, make_xform(L), P,
                                ctx->ovf16, region_shift, k);
         } else {
             auto kern = rsx_count16top_kernel<ES, false>;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            ensure_lds(ctx, reinterpret_cast<const void*>(kern), 131072);
             hipLaunchKernelGGL(kern, dim3(parts), dim3(1024), 131072, st, static_cast<const Elem<ES>*>(src), (uint64_t)n, plan, make_xform(L), P,
                                ctx->ovf16, region_shift, k);
         }
@@ -480,7 +476,7 @@ int launch_bucket16(rsx_ctx* ctx, void* data, void* scratch, size_t n, const rsx
             static_assert(cape<ES, K, WGS>() == bucket_cape(ES, K, WGS), "host and device agree on what a workgroup holds");
             const size_t lds = (size_t)cape<ES, K, WGS>() * ES + (WGS / 64) * RADIX * bucket_cnt_bytes(ES) + 64 + 3 * RADIX * sizeof(uint32_t);
             auto kern = rsx_bucket16_kernel<ES, K, WGS>;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            ensure_lds(ctx, reinterpret_cast<const void*>(kern), lds);
             int per_cu = (int)((size_t)163840 / lds);
             if (per_cu < 1) per_cu = 1;
             if (per_cu > 4 * RSX_B16_WAVES(WGS) * 64 / WGS) per_cu = 4 * RSX_B16_WAVES(WGS) * 64 / WGS;

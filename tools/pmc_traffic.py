@@ -20,15 +20,19 @@ for wl, (t, logn, *_r) in bench.WORKLOADS.items():
     tot = {("sweep", "FETCH_SIZE"): [0.0, 0], ("sweep", "WRITE_SIZE"): [0.0, 0], ("hist", "FETCH_SIZE"): [0.0, 0]}
     per_kernel = {}  # kernel -> {counter: per-dispatch KB}: the paths without a sweep (counting, middle-size split)
     disp = {}        # kernel -> dispatches
+    sums = {}        # kernel -> {counter: total KB over all its instantiations}
     for line in open(f):
         m = re.match(r".*rsx_(sweep|hist)_kernel<.*>\s+(\w+)\s+total\s+(\S+)\s+per-dispatch\s+\S+\s+dispatches\s+(\d+)", line)
         if m and (m.group(1), m.group(2)) in tot:
             tot[(m.group(1), m.group(2))][0] += float(m.group(3))
             tot[(m.group(1), m.group(2))][1] += int(m.group(4))
-        m = re.match(r".*(rsx_\w+_kernel)(?:<[^>]*>)?\s+(FETCH_SIZE|WRITE_SIZE)\s+total\s+\S+\s+per-dispatch\s+(\S+)\s+dispatches\s+(\d+)", line)
+        m = re.match(r".*(rsx_\w+_kernel)(?:<[^>]*>)?\s+(FETCH_SIZE|WRITE_SIZE)\s+total\s+(\S+)\s+per-dispatch\s+(\S+)\s+dispatches\s+(\d+)", line)
         if m:
-            per_kernel.setdefault(m.group(1), {})[m.group(2)] = float(m.group(3))
-            disp[m.group(1)] = int(m.group(4))
+            per_kernel.setdefault(m.group(1), {})[m.group(2)] = float(m.group(4))
+            disp[m.group(1)] = int(m.group(5))
+            # several instantiations of one kernel (the hybrid's bucket kernel: every form is enqueued, one runs): totals
+            sums.setdefault(m.group(1), {}).setdefault(m.group(2), 0.0)
+            sums[m.group(1)][m.group(2)] += float(m.group(3))
     d = bench.digits_for(rs, t)
     n = 1 << logn
     if not tot[("sweep", "FETCH_SIZE")][1]:  # no sweep in this path: HBM bytes of the whole sort, all its kernels
@@ -42,7 +46,7 @@ for wl, (t, logn, *_r) in bench.WORKLOADS.items():
     hybrid = "rsx_bucket16_kernel" in per_kernel
     if hybrid:  # the wide-key hybrid: per sort 2 sweeps run, the launches of the refused sequence return at once (no traffic)
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
-            tot[("sweep", c)][1] = 2 * disp["rsx_bucket16_kernel"]
+            tot[("sweep", c)][1] = 2 * disp["rsx_count16top_kernel"]
     fetch = tot[("sweep", "FETCH_SIZE")][0] / tot[("sweep", "FETCH_SIZE")][1]
     write = tot[("sweep", "WRITE_SIZE")][0] / tot[("sweep", "WRITE_SIZE")][1]
     hist = tot[("hist", "FETCH_SIZE")][0] / max(1, tot[("hist", "FETCH_SIZE")][1])
@@ -57,7 +61,7 @@ for wl, (t, logn, *_r) in bench.WORKLOADS.items():
         out[wl].pop("hist_kernel_fetch_size_kb_raw"); out[wl].pop("hist_calibration_2x_fetch_over_bytes"); out[wl].pop("hist_kernel_bytes_read")
         out[wl]["path"] = "wide-key hybrid: sweep figures are per REAL sweep launch (2 per sort)"
         for kn in ("rsx_bucket16_kernel", "rsx_count16top_kernel"):
-            k = per_kernel.get(kn, {})
+            k = {c: v / max(1, disp.get("rsx_count16top_kernel", 1)) for c, v in sums.get(kn, {}).items()}  # per SORT: one real launch each
             out[wl][kn.replace("rsx_", "").replace("_kernel", "")] = {
                 "traffic_bytes_per_launch": int(round((2 * k.get("FETCH_SIZE", 0.0) + k.get("WRITE_SIZE", 0.0)) * 1024)),
                 "array_bytes": n * d.elem_bytes}
