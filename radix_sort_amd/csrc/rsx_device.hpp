@@ -295,6 +295,7 @@ __device__ __forceinline__ bool gate_open(const Gate& g) {
 // bits 4-5 say which form of the bucket kernel (all are enqueued, each behind its own gate): the smallest workgroup that
 // holds all but a handful of the buckets.
 constexpr uint32_t VERDICT_HYBRID = 1u, VERDICT_LSD = 2u, VERDICT_PATH_MASK = 3u;
+constexpr uint32_t VERDICT_MEDIUM = 0x40u;  // some buckets exceed the chosen form's workgroup: rsx_bucket16_medium_kernel takes those
 constexpr uint32_t VERDICT_WG256 = 0x00u, VERDICT_WG512 = 0x10u, VERDICT_WG1024 = 0x20u, VERDICT_GROUPS = 0x30u, VERDICT_FORM_MASK = 0x30u;
 
 // The plan of a wide-key hybrid sort, made on the device from a sample of the array (rsx_wideplan_kernel) and read by
@@ -317,6 +318,8 @@ struct WidePlan {
     uint32_t scan_cnt[8]; // rsx_scan16_kernel's workgroups add up here: [0..2] buckets above what 256 / 512 / 1024 threads hold,
                           // [3..7] groups of 2^(g) buckets, g = 2 .. 6, above what 512 hold; [scan_done] how many have (zeroed by the plan kernel)
     uint32_t scan_done;
+    uint32_t scan_max;    // the largest bucket (saturated)
+    unsigned long long scan_big;  // elements in buckets above what the largest workgroup holds
 };
 
 // --------------------------------------------------------------- histogram --

@@ -488,8 +488,17 @@ int launch_bucket16(rsx_ctx* ctx, void* data, void* scratch, size_t n, const rsx
         if (gs >= 2) go(integral_constant<int, 512>{}, integral_constant<int, KPT>{}, VERDICT_GROUPS, gs);
         if (avg <= (uint64_t)256 * KPT) go(integral_constant<int, 256>{}, integral_constant<int, KPT>{}, VERDICT_WG256, 0);
         if (avg <= (uint64_t)512 * KPT) go(integral_constant<int, 512>{}, integral_constant<int, KPT>{}, VERDICT_WG512, 0);
-        if (KBIG != KPT && wide_big_form(ES, n)) go(integral_constant<int, 1024>{}, integral_constant<int, KBIG>{}, VERDICT_WG1024, 0);
+        const bool big_form = KBIG != KPT && wide_big_form(ES, n);
+        if (big_form) go(integral_constant<int, 1024>{}, integral_constant<int, KBIG>{}, VERDICT_WG1024, 0);
         else go(integral_constant<int, 1024>{}, integral_constant<int, KPT>{}, VERDICT_WG1024, 0);
+        {   // the buckets above the chosen form's workgroup (VERDICT_MEDIUM): one workgroup of the largest kind each
+            const size_t lds = (size_t)cape<ES, KBIG, 1024>() * ES + 16 * RADIX * bucket_cnt_bytes(ES) + 64 + 3 * RADIX * sizeof(uint32_t);
+            auto kern = rsx_bucket16_medium_kernel<ES, KBIG, 1024>;
+            ensure_lds(ctx, reinterpret_cast<const void*>(kern), lds);
+            const Gate g{base.word, VERDICT_PATH_MASK | VERDICT_MEDIUM, VERDICT_HYBRID | VERDICT_MEDIUM};
+            hipLaunchKernelGGL(kern, dim3((uint32_t)ctx->num_cu), dim3(1024), lds, st, a, starts, scratch, plan, (uint32_t)(256 * KPT), (uint32_t)(512 * KPT),
+                               (uint32_t)(big_form ? cape<ES, KBIG, 1024>() : cape<ES, KPT, 1024>()), g);
+        }
         RSX_HIP(hipGetLastError());
         return RSX_OK;
     }

@@ -261,6 +261,8 @@ __global__ __launch_bounds__(1024) void rsx_wideplan_kernel(const Elem<ES>* __re
     plan->violation = violation;
     for (int i = 0; i < 8; ++i) plan->scan_cnt[i] = 0;
     plan->scan_done = 0;
+    plan->scan_max = 0;
+    plan->scan_big = 0;
 #pragma unroll
     for (int w = 0; w < 8; ++w) {
         plan->ref[w] = w < NW ? first.w[w < NW ? w : 0] : 0u;

@@ -222,8 +222,8 @@ __global__ __launch_bounds__(256) void rsx_total16_kernel(const uint32_t* __rest
 // no faster; 12 % of a 2^23-key sort.)
 __global__ __launch_bounds__(256) void rsx_scan16_kernel(const uint64_t* __restrict__ tot, const uint64_t* __restrict__ BT,
                                                          uint64_t* __restrict__ starts, uint64_t cap256, uint64_t cap512, uint64_t cap1024,
-                                                         uint32_t gs_max, uint32_t forced, WidePlan* __restrict__ plan,
-                                                         uint32_t* __restrict__ host_verdict) {
+                                                         uint32_t gs_max, uint32_t forced, uint64_t medium_max, uint64_t crowd_max,
+                                                         WidePlan* __restrict__ plan, uint32_t* __restrict__ host_verdict) {
     __shared__ uint64_t ws[4], wb[4];
     __shared__ uint32_t s_last;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, b = blockIdx.x;
@@ -249,7 +249,16 @@ __global__ __launch_bounds__(256) void rsx_scan16_kernel(const uint64_t* __restr
         sum += __shfl_xor(sum, 1 << (g - 1));  // every lane: the sum of its aligned group of 2^g bins
         if (g >= 2) og[g] = (uint32_t)__popcll(__ballot((lane & ((1u << g) - 1u)) == 0u && sum > cap512));
     }
+    uint64_t big = c, crowd = c > cap1024 ? c : 0ull;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t y = __shfl_xor(big, o);
+        big = y > big ? y : big;
+        crowd += __shfl_xor(crowd, o);
+    }
     if (lane == 0) {
+        atomicMax(&plan->scan_max, big > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)big);
+        if (crowd) atomicAdd(&plan->scan_big, (unsigned long long)crowd);
         if (o256) atomicAdd(&plan->scan_cnt[0], o256);
         if (o512) atomicAdd(&plan->scan_cnt[1], o512);
         if (o1024) atomicAdd(&plan->scan_cnt[2], o1024);
@@ -282,12 +291,18 @@ __global__ __launch_bounds__(256) void rsx_scan16_kernel(const uint64_t* __restr
     for (uint32_t g = gs_max <= 6u ? gs_max : 6u; g >= 2u && gshift == 0u; --g)
         if (cnt[1 + g] <= FEW) gshift = g;
     plan->group_shift = gshift;
+    // Buckets above the chosen form's workgroup go to rsx_bucket16_medium_kernel (one pass through memory that splits
+    // them by their next bits, then LDS; one workgroup each, a tenth of the other kernel's rate per element): tolerable
+    // for a handful, the largest at most `medium_max` (eight more bits bring it down to a workgroup's size), together at
+    // most `crowd_max` elements (n / 64), else -- unless the hybrid is forced -- the LSD passes run.
+    const uint32_t biggest = __hip_atomic_load(&plan->scan_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t v;
-    if (violation != 0 || (n1024 != 0 && !forced)) v = VERDICT_LSD;
+    const uint64_t crowded = __hip_atomic_load(&plan->scan_big, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (violation != 0 || (!forced && (n1024 > FEW || (n1024 != 0 && ((uint64_t)biggest > medium_max || crowded > crowd_max))))) v = VERDICT_LSD;
     else if (gshift != 0 && n512 == 0) v = VERDICT_HYBRID | VERDICT_GROUPS;
-    else if (n256 <= FEW) v = VERDICT_HYBRID | VERDICT_WG256;
-    else if (n512 <= FEW) v = VERDICT_HYBRID | VERDICT_WG512;
-    else v = VERDICT_HYBRID | VERDICT_WG1024;
+    else if (n256 <= FEW) v = VERDICT_HYBRID | VERDICT_WG256 | (n256 ? VERDICT_MEDIUM : 0u);
+    else if (n512 <= FEW) v = VERDICT_HYBRID | VERDICT_WG512 | (n512 ? VERDICT_MEDIUM : 0u);
+    else v = VERDICT_HYBRID | VERDICT_WG1024 | (n1024 ? VERDICT_MEDIUM : 0u);
     plan->verdict = v;
     __hip_atomic_store(host_verdict, (v & VERDICT_HYBRID) ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // the host's forecast for later sorts
 }

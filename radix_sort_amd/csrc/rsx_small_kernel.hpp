@@ -209,8 +209,12 @@ __device__ __forceinline__ void local_sort(const SmallArgs& a, const Elem<ES>* _
 // `buf1`) between the bucket's ranges of the two buffers, each pass a count, a scan and a scatter of mod.rs:90-168 with
 // chunk == WG * KPT elements taken in order (stable ranks inside the chunk as in local_sort, running cursors across
 // chunks).  Slow (one CU for the whole bucket) and rare: the context falls back to LSD passes for its next sorts.
-template <int ES, int KPT, int WG>
-__device__ void big_bucket_sort(const SmallArgs& a, Elem<ES>* buf0, Elem<ES>* buf1, const uint32_t m, unsigned char* smem) {
+// One pass through memory by ONE workgroup: src[0, m) -> dst[0, m), a stable partition by digit(x) in [0, 256) -- count,
+// scan and chunk-wise stable scatter (mod.rs:90-168 with chunk == what the workgroup holds in LDS).  Thread t < 256 gets
+// its digit's start and count.  map_back: signed / float keys are mapped back on the way out.
+template <int ES, int KPT, int WG, typename DigitFn>
+__device__ __forceinline__ void stream_pass(const SmallArgs& a, const Elem<ES>* __restrict__ src, Elem<ES>* __restrict__ dst, const uint32_t m,
+                                            unsigned char* smem, DigitFn digit, const bool map_back, uint32_t& bin_start, uint32_t& bin_count) {
     constexpr int NWAVE = WG / WAVE;
     constexpr uint32_t CH = cape<ES, KPT, WG>();
     using E = Elem<ES>;
@@ -218,115 +222,121 @@ __device__ void big_bucket_sort(const SmallArgs& a, Elem<ES>* buf0, Elem<ES>* bu
     using C = WaveCnt<ES>;
     typename C::T* s_cnt = reinterpret_cast<typename C::T*>(smem + (size_t)cape<ES, KPT, WG>() * sizeof(E));
     uint32_t* s_misc = reinterpret_cast<uint32_t*>(s_cnt + NWAVE * RADIX);  // [NWAVE]
-    uint32_t* s_gbase = s_misc + NWAVE;        // [256] where the next element of each digit goes, relative to the bucket
+    uint32_t* s_gbase = s_misc + NWAVE;        // [256] where the next element of each digit goes, relative to the array
     uint32_t* s_dstart = s_gbase + RADIX;      // [256] start of each digit's run in the sorted chunk
     uint32_t* s_dcount = s_dstart + RADIX;     // [256] its length
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     typename C::T* my = s_cnt + wave * RADIX;
+    if (tid < RADIX) s_gbase[tid] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < m; i += WG) atomicAdd(&s_gbase[digit(src[i])], 1u);  // count (mod.rs:90-109)
+    __syncthreads();
+    if (tid < RADIX) {  // prefix (mod.rs:110-120)
+        const uint32_t c = s_gbase[tid];
+        const uint32_t incl = wave_incl_scan<true>(c);
+        if (lane == 63) s_misc[wave] = incl;
+        s_dcount[tid] = incl - c;
+        bin_count = c;
+    }
+    __syncthreads();
+    if (tid < RADIX) {
+        uint32_t b = s_dcount[tid];
+        for (uint32_t w = 0; w < wave; ++w) b += s_misc[w];
+        s_gbase[tid] = b;
+        bin_start = b;
+    }
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < m; c0 += CH) {  // scatter (mod.rs:121-168), chunk by chunk in order
+        const uint32_t n = m - c0 < CH ? m - c0 : CH;
+        const uint32_t kp = (n + WG - 1) / WG;
+        const uint32_t seg = wave * (WAVE * kp) + lane;
+        E e[KPT];
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            e[j] = E{};
+            if ((uint32_t)j < kp) {
+                const uint32_t p = seg + (uint32_t)j * WAVE;
+                if (p < n) e[j] = src[c0 + p];
+            }
+        }
+        C::zero(my, lane);
+        auto digit_of = [&](int j) -> uint32_t { return (seg + (uint32_t)j * WAVE >= n) ? 255u : digit(e[j]); };
+        uint32_t rk[KPT];
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            rk[j] = 0;
+            if ((uint32_t)j < kp) {
+                const uint32_t d = digit_of(j);
+                const uint64_t mm = match_digit(d);  // (ballots: the rare path does not depend on the LDS ordering self-test)
+                const uint32_t below = mbcnt64(mm);
+                const uint32_t seen = my[d];
+                if (below == 0) (void)C::add_rtn(my, d, (uint32_t)__popcll(mm));
+                rk[j] = seen + below;
+            }
+        }
+        __syncthreads();
+        uint32_t tcount = 0, incl = 0;
+        if (tid < RADIX) {
+#pragma unroll
+            for (int w = 0; w < NWAVE; ++w) tcount += s_cnt[w * RADIX + tid];
+            incl = wave_incl_scan<true>(tcount);
+            if (lane == 63) s_misc[wave] = incl;
+        }
+        __syncthreads();
+        if (tid < RADIX) {
+            uint32_t run = incl - tcount;
+            for (uint32_t w = 0; w < wave; ++w) run += s_misc[w];
+            s_dstart[tid] = run;
+            s_dcount[tid] = tid == RADIX - 1 ? tcount - (kp * WG - n) : tcount;  // padding slots rank as digit 255, last
+#pragma unroll
+            for (int w = 0; w < NWAVE; ++w) {
+                const uint32_t c = s_cnt[w * RADIX + tid];
+                s_cnt[w * RADIX + tid] = (typename C::T)run;
+                run += c;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KPT; ++j)
+            if ((uint32_t)j < kp) {
+                // (padding slots, digit 255, rank last and land past n: inside LDS only if it has all WG * KPT slots)
+                if constexpr (cape<ES, KPT, WG>() < (uint32_t)WG * KPT) {
+                    if (seg + (uint32_t)j * WAVE < n) s_elems[(uint32_t)my[digit_of(j)] + rk[j]] = e[j];
+                } else {
+                    s_elems[(uint32_t)my[digit_of(j)] + rk[j]] = e[j];
+                }
+            }
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += WG) {
+            E x = s_elems[i];
+            const uint32_t d = digit(x);
+            const uint32_t pos = s_gbase[d] + (i - s_dstart[d]);
+            if (map_back) key_map<ES, true>(x, a.xf);
+            dst[pos] = x;
+        }
+        __syncthreads();
+        if (tid < RADIX) s_gbase[tid] += s_dcount[tid];
+        __syncthreads();
+    }
+    // whoever reads dst next does so through this CU's vector L1: write back, meet, and drop what the L1 holds
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+template <int ES, int KPT, int WG>
+__device__ void big_bucket_sort(const SmallArgs& a, Elem<ES>* buf0, Elem<ES>* buf1, const uint32_t m, unsigned char* smem) {
+    using E = Elem<ES>;
     E* src = buf0;
     E* dst = buf1;
     for (uint32_t pass = 0; pass < a.passes; ++pass) {
         const DigitSpec spec = a.spec[pass];
-        const bool last = pass + 1 == a.passes;
-        if (tid < RADIX) s_gbase[tid] = 0;
-        __syncthreads();
-        for (uint32_t i = tid; i < m; i += WG) atomicAdd(&s_gbase[elem_digit<ES, false>(src[i], spec)], 1u);  // count (mod.rs:90-109)
-        __syncthreads();
-        if (tid < RADIX) {  // prefix (mod.rs:110-120)
-            const uint32_t c = s_gbase[tid];
-            const uint32_t incl = wave_incl_scan<true>(c);
-            if (lane == 63) s_misc[wave] = incl;
-            s_dcount[tid] = incl - c;
-        }
-        __syncthreads();
-        if (tid < RADIX) {
-            uint32_t b = s_dcount[tid];
-            for (uint32_t w = 0; w < wave; ++w) b += s_misc[w];
-            s_gbase[tid] = b;
-        }
-        __syncthreads();
-        for (uint32_t c0 = 0; c0 < m; c0 += CH) {  // scatter (mod.rs:121-168), chunk by chunk in order
-            const uint32_t n = m - c0 < CH ? m - c0 : CH;
-            const uint32_t kp = (n + WG - 1) / WG;
-            const uint32_t seg = wave * (WAVE * kp) + lane;
-            E e[KPT];
-#pragma unroll
-            for (int j = 0; j < KPT; ++j) {
-                e[j] = E{};
-                if ((uint32_t)j < kp) {
-                    const uint32_t p = seg + (uint32_t)j * WAVE;
-                    if (p < n) e[j] = src[c0 + p];
-                }
-            }
-            C::zero(my, lane);
-            auto digit_of = [&](int j) -> uint32_t {
-                return (seg + (uint32_t)j * WAVE >= n) ? 255u : elem_digit<ES, false>(e[j], spec);
-            };
-            uint32_t rk[KPT];
-#pragma unroll
-            for (int j = 0; j < KPT; ++j) {
-                rk[j] = 0;
-                if ((uint32_t)j < kp) {
-                    const uint32_t d = digit_of(j);
-                    const uint64_t mm = match_digit(d);  // (ballots: the rare path does not depend on the LDS ordering self-test)
-                    const uint32_t below = mbcnt64(mm);
-                    const uint32_t seen = my[d];
-                    if (below == 0) (void)C::add_rtn(my, d, (uint32_t)__popcll(mm));
-                    rk[j] = seen + below;
-                }
-            }
-            __syncthreads();
-            uint32_t tcount = 0, incl = 0;
-            if (tid < RADIX) {
-#pragma unroll
-                for (int w = 0; w < NWAVE; ++w) tcount += s_cnt[w * RADIX + tid];
-                incl = wave_incl_scan<true>(tcount);
-                if (lane == 63) s_misc[wave] = incl;
-            }
-            __syncthreads();
-            if (tid < RADIX) {
-                uint32_t run = incl - tcount;
-                for (uint32_t w = 0; w < wave; ++w) run += s_misc[w];
-                s_dstart[tid] = run;
-                s_dcount[tid] = tid == RADIX - 1 ? tcount - (kp * WG - n) : tcount;  // padding slots rank as digit 255, last
-#pragma unroll
-                for (int w = 0; w < NWAVE; ++w) {
-                    const uint32_t c = s_cnt[w * RADIX + tid];
-                    s_cnt[w * RADIX + tid] = (typename C::T)run;
-                    run += c;
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < KPT; ++j)
-                if ((uint32_t)j < kp) {
-                    // (padding slots, digit 255, rank last and land past n: inside LDS only if it has all WG * KPT slots)
-                    if constexpr (cape<ES, KPT, WG>() < (uint32_t)WG * KPT) {
-                        if (seg + (uint32_t)j * WAVE < n) s_elems[(uint32_t)my[digit_of(j)] + rk[j]] = e[j];
-                    } else {
-                        s_elems[(uint32_t)my[digit_of(j)] + rk[j]] = e[j];
-                    }
-                }
-            __syncthreads();
-            for (uint32_t i = tid; i < n; i += WG) {
-                E x = s_elems[i];
-                const uint32_t d = elem_digit<ES, false>(x, spec);
-                const uint32_t pos = s_gbase[d] + (i - s_dstart[d]);
-                if (last && a.map_store) key_map<ES, true>(x, a.xf);
-                dst[pos] = x;
-            }
-            __syncthreads();
-            if (tid < RADIX) s_gbase[tid] += s_dcount[tid];
-            __syncthreads();
-        }
+        uint32_t bs = 0, bc = 0;
+        stream_pass<ES, KPT, WG>(a, src, dst, m, smem, [&](const E& x) { return elem_digit<ES, false>(x, spec); },
+                                 pass + 1 == a.passes && a.map_store != 0, bs, bc);
         E* t = src;
         src = dst;
         dst = t;
-        // the next pass reads, through this CU's vector L1, what this pass wrote (and two passes on, addresses that
-        // were read before they were rewritten): write back, meet, and drop what the L1 holds
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
 }
 
@@ -544,6 +554,7 @@ __global__ __launch_bounds__(WG, RSX_B16_WAVES(WG)) void rsx_bucket16_kernel(con
     // would cover a 4.6 us round trip of 31 per bucket on 2^30 u64, but every form of that loop tried spilled 50-370
     // registers and ran slower.)
     const uint32_t gs = a.group_shift != 0 ? plan->group_shift : 0;  // (the host offers groups up to 2^a.group_shift; rsx_scan16_kernel chose)
+    const bool medium = (plan->verdict & VERDICT_MEDIUM) != 0;
     PassPlan pp;  // (uniform: scalar loads and registers)
     pp.end = gs == 0 ? plan->pass_end : plan->group_end;
     if (pp.end == 0) {  // the window reaches the key's lowest bit: the two sweeps were the sort; signed / float keys are still mapped
@@ -590,12 +601,95 @@ __global__ __launch_bounds__(WG, RSX_B16_WAVES(WG)) void rsx_bucket16_kernel(con
                     if (!whole) pp.first = 0;
                     local_sort_skip<ES, KPT, WG>(a, bucket, bucket, (uint32_t)count, smem, pp, s_flag);
                     if (!whole) pp.first = first;
-                } else {  // an even number of passes: ends where it began
+                } else if (!medium) {  // (never: a bucket above what this workgroup holds makes the verdict VERDICT_MEDIUM, and
+                                       // rsx_bucket16_medium_kernel takes it; without this branch the compiler spills 34 registers here)
                     big_bucket_sort<ES, KPT, WG>(a, bucket, static_cast<E*>(scratch) + start, (uint32_t)count, smem);
                 }
             }
             __syncthreads();  // smem belongs to the next bucket
         }
+    }
+}
+
+// The buckets ABOVE what the workgroup of the chosen form holds (a handful in an input whose density varies; all of them
+// in an array too large for its 65536 buckets to fit LDS).  One workgroup per such bucket: ONE pass through memory
+// (stream_pass, data -> scratch) splits it by its next k bits -- as many as bring the parts down to about 0.6 of what this
+// workgroup holds, at most 8 --, then every part is sorted in LDS (scratch -> data, its final place).  A part that is
+// still too large, or a bucket that eight bits do not bring down, goes through memory pass by pass (big_bucket_sort).
+template <int ES, int KPT, int WG>
+__global__ __launch_bounds__(WG, RSX_B16_WAVES(WG)) void rsx_bucket16_medium_kernel(const SmallArgs a, const uint64_t* __restrict__ starts, void* scratch,
+                                                                                const WidePlan* __restrict__ plan, uint32_t cap256, uint32_t cap512,
+                                                                                uint32_t cap1024, Gate gate) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t s_part[2];
+    if (!gate_open(gate)) return;
+    using E = Elem<ES>;
+    constexpr int NWAVE = WG / WAVE;
+    constexpr uint32_t CAPE = cape<ES, KPT, WG>();
+    uint32_t* s_flag = reinterpret_cast<uint32_t*>(reinterpret_cast<typename WaveCnt<ES>::T*>(smem + (size_t)CAPE * sizeof(E)) + NWAVE * RADIX) + NWAVE;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t form = plan->verdict & VERDICT_FORM_MASK;
+    const uint64_t handled = form == VERDICT_WG256 ? cap256 : form == VERDICT_WG1024 ? cap1024 : cap512;  // what the other kernel took
+    const uint32_t end = plan->pass_end;
+    if (end == 0) return;  // nothing below the window to sort by (the other kernel mapped the keys back)
+    const uint32_t b_lo = plan->window_top - 15u;  // key bits below the window
+    for (uint32_t b = blockIdx.x; b < 65536u; b += gridDim.x) {
+        const uint64_t start = starts[b];
+        const uint64_t count = starts[b + 1] - start;  // (the same for every thread: uniform control flow below)
+        if (count <= handled) continue;
+        E* bucket = static_cast<E*>(a.data) + start;
+        E* scr = static_cast<E*>(scratch) + start;
+        uint32_t k = 0;
+        while (k < 8u && (count >> k) > (uint64_t)CAPE * 6u / 10u) ++k;
+        if (k > b_lo) k = b_lo;
+        if (k == 0 || (count >> k) > (uint64_t)CAPE || count > 0xFFFFFFFFull) {
+            big_bucket_sort<ES, KPT, WG>(a, bucket, scr, (uint32_t)count, smem);  // (an even number of passes: ends where it began)
+            __syncthreads();
+            continue;
+        }
+        DigitSpec sp{};
+        const uint32_t ebit = 8u * a.key_offset + b_lo - k;
+        sp.word = ebit >> 5;
+        sp.shift = ebit & 31u;
+        const uint32_t kmask = (1u << k) - 1u;
+        uint32_t part_start = 0, part_count = 0;
+        stream_pass<ES, KPT, WG>(a, bucket, scr, (uint32_t)count, smem, [&](const E& x) { return elem_digit_any<ES>(x, sp) & kmask; }, false, part_start,
+                                 part_count);
+        // the parts' passes: as a bucket's, one digit more when the split took half a digit of their distinguishing bits
+        PassPlan pp;
+        pp.end = end;
+        const uint32_t keep = plan->keep + (k >= 4u ? 1u : 0u);
+        pp.first = (end > keep && !a.no_skip) ? end - keep : 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            uint32_t mk = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                const uint32_t byte = 4u * (uint32_t)w + q;
+                if (byte >= a.key_offset + pp.first && byte < a.key_offset + a.key_bytes) mk |= 0xFFu << (8u * q);
+            }
+            pp.mask[w] = mk;
+        }
+        for (uint32_t j = 0; j <= kmask; ++j) {
+            __syncthreads();
+            if (tid == j) {
+                s_part[0] = part_start;
+                s_part[1] = part_count;
+            }
+            __syncthreads();
+            const uint32_t off = s_part[0], cnt = s_part[1];
+            if (cnt == 0) continue;
+            if (cnt <= CAPE) {
+                local_sort_skip<ES, KPT, WG>(a, scr + off, bucket + off, cnt, smem, pp, s_flag);
+            } else {  // still too large (its keys crowd on few values of those bits): back to its place, then pass by pass
+                for (uint32_t i = tid; i < cnt; i += WG) bucket[off + i] = scr[off + i];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __syncthreads();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                big_bucket_sort<ES, KPT, WG>(a, bucket + off, scr + off, cnt, smem);
+            }
+        }
+        __syncthreads();  // smem belongs to the next bucket
     }
 }
 

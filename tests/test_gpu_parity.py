@@ -286,6 +286,37 @@ def test_wide_key_hybrid_picks_its_workgroups_by_the_largest_buckets(rs, torch, 
     c.close()
 
 
+@pytest.mark.parametrize("t", ["u64", "(u64,u64)", "i64"])
+def test_wide_key_hybrid_a_handful_of_crowded_buckets(rs, torch, orc, t):
+    """Uniform keys plus a few values of the top 16 bits that hold more elements than any workgroup sorts in LDS.  The
+    verdict keeps the hybrid (VERDICT_MEDIUM) and the medium kernel takes those: one pass through memory that splits
+    each by its next bits, then LDS.  (More than a handful, one too large for eight more bits, or more than n / 64
+    elements in them: the LSD passes -- the Zipf case of the tests above.)"""
+    d = _digits(rs, t)
+    es, ko, kb, _kind = util.TYPES[t]
+    lay = orc.Layout(*util.TYPES[t])
+    c = rs.Context(torch.cuda.current_device())
+    c.set_option(rs.OPT_WIDE_SORT, 3)
+    n = _mid_max(es) + 200001
+    rng = np.random.default_rng(909 + es)
+    key = rng.integers(0, 256, size=(n, kb), dtype=np.uint8)
+    nhot, each = (3, 19000) if es == 8 else (2, 8000)  # above the largest workgroup (17408 / 7168), together under n / 64
+    hot = rng.choice(n, size=nhot * each, replace=False).reshape(nhot, each)
+    for j in range(nhot):
+        key[hot[j], kb - 2:] = rng.integers(0, 256, size=2, dtype=np.uint8)  # one value of the top 16 bits
+    raw = np.zeros((n, es), dtype=np.uint8)
+    raw[:, ko:ko + kb] = key
+    idx = np.arange(n, dtype=np.uint64).view(np.uint8).reshape(n, 8)
+    for j, b in enumerate(b for b in range(es) if not ko <= b < ko + kb):
+        raw[:, b] = idx[:, j] if j < 8 else 0
+    x = torch.from_numpy(raw.reshape(-1).copy()).cuda()
+    rs.radix_sort(x, digits=d, ctx=c)
+    c.check()
+    assert (c.get_info(rs.INFO_LAST_PASSES) >> 24) & 15 == 5, t
+    assert np.array_equal(x.cpu().numpy(), orc.sort_parallel(raw.reshape(-1), lay, 8)), t
+    c.close()
+
+
 def test_wide_key_hybrid_decides_on_the_device(rs, torch, ctx, orc):
     """Default mode at a size where the hybrid is tried (2 GiB of u64): a uniform input takes it, a Zipf input is
     refused by the count (the LSD passes run, gated on the same verdict word), and after a refusal the context goes
