@@ -319,9 +319,8 @@ int launch_mid_split(rsx_ctx* ctx, const void* src, void* dst, size_t n, const r
 inline void set_skip_mask(rsx_ctx* ctx, SmallArgs& a, const rsx_layout* L, uint32_t keep = 4) {
     a.no_skip = ctx->bucket_no_skip;
     a.keep = keep;
-    std::memset(a.cmp_mask, 0, sizeof a.cmp_mask);
-    if (a.passes > keep && !a.no_skip)
-        for (uint32_t byte = L->key_offset + a.passes - keep; byte < L->key_offset + L->key_bytes; ++byte) a.cmp_mask[byte >> 2] |= 0xFFu << (8 * (byte & 3));
+    a.key_offset = L->key_offset;  // (the kernel builds its compare masks from these)
+    a.key_bytes = L->key_bytes;
 }
 
 template <int ES>

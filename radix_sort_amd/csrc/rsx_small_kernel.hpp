@@ -9,7 +9,7 @@
 //                          the array by a 16-bit window of the key; persistent workgroups sort the 65536 buckets (or
 //                          groups of small ones) by the digits below it.
 //  Both bucket kernels start their passes at the digit that leaves four or five (PassPlan) and mend the few
-//  neighbours that still agree afterwards by the skipped digits (local_finish, local_mend).
+//  neighbours that still agree afterwards by the skipped digits (local_finish, mend_listed).
 //
 // The general path costs a memset, a count kernel and D sweeps whatever the size (>= 10 us each: a sweep of one
 // tile still walks its roll call, cursors and flush): 70 us for 1000 u32 keys, 110 us for 2^20.  Here the
@@ -39,9 +39,8 @@ struct SmallArgs {
     uint32_t cap;                     // elements a 1024-thread workgroup sorts in LDS (a 256-thread one: a quarter)
     uint32_t no_skip;                 // bucket16 kernel: run every pass (1), or start at the digit that leaves four and mend (0)
     uint32_t keep;                    // ... how many passes that start leaves (4; 5 for groups of buckets)
-    uint32_t cmp_mask[8];             // ... the bits of the key from that digit up, per element dword
     uint32_t group_shift;             // bucket16 kernel: a workgroup takes 2^group_shift consecutive buckets as ONE array
-    uint32_t key_offset, key_bytes;   // bucket16 kernel: where the key sits in the element (it builds its own compare mask)
+    uint32_t key_offset, key_bytes;   // bucket kernels: where the key sits in the element (they build their compare masks: PassPlan)
     uint32_t* hint;                   // host-visible report for the host's next forecast: 1 = every bucket of this input fits a
                                       // 256-thread workgroup, 3 = a 1024-thread one, 2 = some bucket fits neither
 };
@@ -50,7 +49,22 @@ struct SmallArgs {
 // the result mended, local_finish), and the key bits from digit `first` up per element dword.  Uniform (scalar registers).
 struct PassPlan {
     uint32_t first, end;
-    uint32_t mask[8];
+    uint32_t mask[8];  // key bytes of digits first .. (what the passes sorted by)
+    uint32_t low[8];   // key bytes of digits 0 .. first-1 (what they skipped)
+    __device__ __forceinline__ void set_masks(const uint32_t key_offset, const uint32_t key_bytes) {
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            uint32_t m = 0, l = 0;
+#pragma unroll
+            for (uint32_t b = 0; b < 4; ++b) {
+                const uint32_t byte = 4u * (uint32_t)w + b;
+                if (byte >= key_offset + first && byte < key_offset + key_bytes) m |= 0xFFu << (8u * b);
+                if (byte >= key_offset && byte < key_offset + first) l |= 0xFFu << (8u * b);
+            }
+            mask[w] = m;
+            low[w] = l;
+        }
+    }
 };
 
 // The per-wave digit counters of these sorts.  (16-bit halves, two to a word, for elements of 12 bytes and more would
@@ -358,55 +372,25 @@ __device__ __forceinline__ bool agree(const PassPlan& pp, const Elem<ES>& x, con
     for (int w = 0; w < ES / 4; ++w) diff |= (x.w[w] ^ y.w[w]) & pp.mask[w];
     return diff == 0;
 }
-// One thread per run sorts it by the skipped digits (stable insertion).  Returns false (for every thread) if some run
-// is too long for that -- the caller then runs all passes on what LDS holds (a stable sort of a permutation whose equal
-// keys are in input order).  Rare: local_finish only comes here when some neighbours agree.
-template <int ES, int WG>
-__device__ __forceinline__ bool local_mend(const SmallArgs& a, const uint32_t n, unsigned char* smem, const PassPlan& pp, uint32_t* s_flag) {
-    const uint32_t f = pp.first;
-    using E = Elem<ES>;
-    constexpr uint32_t MAX_RUN = 48;
-    E* s_elems = reinterpret_cast<E*>(smem);
-    auto less = [&](const E& x, const E& y) {  // by digits f-1 .. 0
-        for (uint32_t d = f; d-- > 0;) {
-            const uint32_t dx = elem_digit<ES, false>(x, a.spec[d]), dy = elem_digit<ES, false>(y, a.spec[d]);
-            if (dx != dy) return dx < dy;
-        }
-        return false;
-    };
-    if (threadIdx.x == 0) *s_flag = 0;
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i + 1 < n; i += WG) {
-        if (i != 0 && agree<ES>(pp, s_elems[i], s_elems[i - 1])) continue;  // not the head of a run
-        if (!agree<ES>(pp, s_elems[i + 1], s_elems[i])) continue;           // a run of one
-        uint32_t len = 2;
-        while (i + len < n && len <= MAX_RUN && agree<ES>(pp, s_elems[i + len], s_elems[i])) ++len;
-        if (len > MAX_RUN) {
-            *s_flag = 1;
-            continue;
-        }
-        for (uint32_t k = 1; k < len; ++k) {  // stable insertion by the skipped digits
-            const E x = s_elems[i + k];
-            uint32_t j = k;
-            while (j > 0 && less(x, s_elems[i + j - 1])) {
-                s_elems[i + j] = s_elems[i + j - 1];
-                --j;
-            }
-            s_elems[i + j] = x;
-        }
-    }
-    __syncthreads();
-    return *s_flag == 0;
+// The usual case of a mend: a few runs of two or three in an array of thousands (a bucket of m keys whose passes covered
+// b bits leaves m^2 / 2^(b+1) agreeing pairs).  The threads that saw a tie list the HEADS of the runs (a tie whose
+// predecessor is not one) in the wave counters' LDS; one thread per listed head sorts its run by the skipped digits, and
+// every thread reads its elements back.  More heads than the list holds, or a run too long for an insertion sort: every
+// pass on what LDS holds (the caller).
+constexpr uint32_t MEND_LIST = 192;
+template <int ES, int KPT, int WG>
+__device__ __forceinline__ uint32_t* mend_count(unsigned char* smem) {
+    return reinterpret_cast<uint32_t*>(smem + (size_t)cape<ES, KPT, WG>() * sizeof(Elem<ES>));  // [0] heads listed, [1 ..] the list
 }
-
 // The end of a bucket whose passes started at digit f > 0: the sorted tile is read back in store order together with
 // every element's predecessor (local_check; true if some neighbours agree); if none do -- the rule -- the registers go
 // straight to memory (local_store_regs).
 template <int ES, int KPT, int WG>
-__device__ __forceinline__ bool local_check(const PassPlan& pp, const uint32_t n, unsigned char* smem, Elem<ES> (&x)[KPT]) {
+__device__ __forceinline__ bool local_check(const PassPlan& pp, const uint32_t n, unsigned char* smem, Elem<ES> (&x)[KPT], uint32_t& ties) {
     using E = Elem<ES>;
     const E* s_elems = reinterpret_cast<const E*>(smem);
-    uint32_t ties = 0;  // (no short-circuit: the reads of all rounds are in flight together)
+    ties = 0;  // bit j: element j * WG + tid agrees with its predecessor (no short-circuit: the reads of all rounds are in flight together)
+    if (threadIdx.x == 0) *mend_count<ES, KPT, WG>(smem) = 0;  // (the wave counters are free after the last pass's barrier)
 #pragma unroll
     for (int j = 0; j < KPT; ++j) {
         const uint32_t i = (uint32_t)j * WG + threadIdx.x;
@@ -417,10 +401,81 @@ __device__ __forceinline__ bool local_check(const PassPlan& pp, const uint32_t n
             uint32_t diff = 0;
 #pragma unroll
             for (int w = 0; w < ES / 4; ++w) diff |= (x[j].w[w] ^ p.w[w]) & pp.mask[w];
-            ties |= (diff == 0 && i != 0) ? 1u : 0u;
+            ties |= (diff == 0 && i != 0) ? 1u << j : 0u;
         }
     }
     return __syncthreads_or(ties != 0 ? 1 : 0) != 0;
+}
+// (Not inlined: inside the bucket kernels' loop its registers cost the 1024- and 512-thread forms 70-86 spilled ones and
+// 2^30 u64 8 %.  It takes what it needs by value -- no argument block, which would go to scratch.)
+#ifndef RSX_MEND_INLINE
+#define RSX_MEND_INLINE __forceinline__
+#endif
+template <int ES>
+struct MendMasks {
+    uint32_t hi[ES / 4], lo[ES / 4];
+};
+template <int ES>
+__device__ RSX_MEND_INLINE uint32_t mend_listed(Elem<ES>* s_elems, uint32_t* s_list, uint32_t* s_flag, const uint32_t n, const uint32_t wg,
+                                                          uint32_t ties, const MendMasks<ES> mm) {
+    using E = Elem<ES>;
+    constexpr uint32_t MAX_RUN = 48;
+    auto same = [&](const E& u, const E& v) {
+        uint32_t diff = 0;
+#pragma unroll
+        for (int w = 0; w < ES / 4; ++w) diff |= (u.w[w] ^ v.w[w]) & mm.hi[w];
+        return diff == 0;
+    };
+    auto less = [&](const E& u, const E& v) {  // by the skipped digits, the highest first: their bytes as one number
+#pragma unroll
+        for (int w = ES / 4 - 1; w >= 0; --w) {
+            const uint32_t a = u.w[w] & mm.lo[w], b = v.w[w] & mm.lo[w];
+            if (a != b) return a < b;
+        }
+        return false;
+    };
+    if (threadIdx.x == 0) *s_flag = 0;
+    for (uint32_t j = 0; ties != 0; ++j, ties >>= 1) {
+        if (!(ties & 1u)) continue;
+        const uint32_t i = j * wg + threadIdx.x;  // agrees with i - 1; is i - 1 the head of the run?
+        if (i >= 2 && same(s_elems[i - 1], s_elems[i - 2])) continue;
+        const uint32_t k = atomicAdd(&s_list[0], 1u);
+        if (k < MEND_LIST) s_list[1 + k] = i - 1;
+    }
+    __syncthreads();
+    const uint32_t heads = s_list[0];
+    if (heads > MEND_LIST) return 0u;  // (nothing was moved yet)
+    if (threadIdx.x < heads) {
+        const uint32_t i = s_list[1 + threadIdx.x];
+        uint32_t len = 2;
+        while (i + len < n && len <= MAX_RUN && same(s_elems[i + len], s_elems[i])) ++len;
+        if (len > MAX_RUN) {
+            *s_flag = 1;
+        } else {
+            for (uint32_t k = 1; k < len; ++k) {  // stable insertion by the skipped digits
+                const E y = s_elems[i + k];
+                uint32_t j = k;
+                while (j > 0 && less(y, s_elems[i + j - 1])) {
+                    s_elems[i + j] = s_elems[i + j - 1];
+                    --j;
+                }
+                s_elems[i + j] = y;
+            }
+        }
+    }
+    __syncthreads();
+    return *s_flag == 0 ? 1u : 0u;
+}
+template <int ES, int KPT, int WG>
+__device__ __forceinline__ bool local_mend_listed(const uint32_t n, unsigned char* smem, const PassPlan& pp, uint32_t* s_flag, const uint32_t ties) {
+    static_assert((WG / WAVE) * RADIX >= MEND_LIST + 1, "the list lives in the wave counters");
+    MendMasks<ES> mm;
+#pragma unroll
+    for (int w = 0; w < ES / 4; ++w) {
+        mm.hi[w] = pp.mask[w];
+        mm.lo[w] = pp.low[w];
+    }
+    return mend_listed<ES>(reinterpret_cast<Elem<ES>*>(smem), mend_count<ES, KPT, WG>(smem), s_flag, n, (uint32_t)WG, ties, mm) != 0;
 }
 template <int ES, int KPT, int WG>
 __device__ __forceinline__ void local_store_regs(const SmallArgs& a, Elem<ES>* __restrict__ dst, const uint32_t n, Elem<ES> (&x)[KPT]) {
@@ -439,11 +494,12 @@ template <int ES, int KPT, int WG>
 __device__ __forceinline__ bool local_finish(const SmallArgs& a, Elem<ES>* __restrict__ dst, const uint32_t n, unsigned char* smem, const PassPlan& pp,
                                              uint32_t* s_flag) {
     Elem<ES> x[KPT];
-    if (!local_check<ES, KPT, WG>(pp, n, smem, x)) {
+    uint32_t ties;
+    if (!local_check<ES, KPT, WG>(pp, n, smem, x, ties)) {
         local_store_regs<ES, KPT, WG>(a, dst, n, x);
         return true;
     }
-    if (!local_mend<ES, WG>(a, n, smem, pp, s_flag)) return false;
+    if (!local_mend_listed<ES, KPT, WG>(n, smem, pp, s_flag, ties)) return false;
     local_store<ES, KPT, WG>(a, dst, n, smem);
     return true;
 }
@@ -526,8 +582,7 @@ __global__ __launch_bounds__(WG) void rsx_bucket_sort_kernel(const SmallArgs a) 
         PassPlan pp;
         pp.end = a.passes;
         pp.first = (a.passes > a.keep && !a.no_skip) ? a.passes - a.keep : 0;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) pp.mask[w] = a.cmp_mask[w];
+        pp.set_masks(a.key_offset, a.key_bytes);
         uint32_t* s_flag = reinterpret_cast<uint32_t*>(reinterpret_cast<typename WaveCnt<ES>::T*>(smem + (size_t)cape<ES, KPT, WG>() * sizeof(Elem<ES>)) + (WG / WAVE) * RADIX) + (WG / WAVE);
         local_sort_skip<ES, KPT, WG>(a, static_cast<const Elem<ES>*>(a.src) + start, static_cast<Elem<ES>*>(a.data) + start, (uint32_t)count, smem, pp,
                                      s_flag);
@@ -545,7 +600,7 @@ __global__ __launch_bounds__(WG, RSX_B16_WAVES(WG)) void rsx_bucket16_kernel(con
     // A bucket of m elements that agree on their window (and everything above it) is, as a rule, told apart by the next
     // 2 log2(m) bits or so: the passes start at the digit that leaves four -- five if the top one reaches into the
     // window -- (32+ bits for at most 2^15 elements), the neighbours that still agree afterwards are put right one run
-    // at a time (local_mend), and a workgroup that meets an input where that does not work -- long runs: few distinct
+    // at a time (mend_listed), and a workgroup that meets an input where that does not work -- long runs: few distinct
     // values in those bits -- runs all passes from then on.
     // Small buckets (2^24 u64 keys: 256 each) cost a workgroup ~8 us apiece whatever they hold.  The host then sets
     // group_shift: 2^group_shift consecutive buckets -- a contiguous range of the final order -- are sorted as ONE array,
@@ -571,16 +626,7 @@ __global__ __launch_bounds__(WG, RSX_B16_WAVES(WG)) void rsx_bucket16_kernel(con
     }
     const uint32_t keep = gs == 0 ? plan->keep : plan->group_keep;
     pp.first = (pp.end > keep && !a.no_skip) ? pp.end - keep : 0;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) {
-        uint32_t m = 0;
-#pragma unroll
-        for (uint32_t b = 0; b < 4; ++b) {
-            const uint32_t byte = 4u * (uint32_t)w + b;
-            if (byte >= a.key_offset + pp.first && byte < a.key_offset + a.key_bytes) m |= 0xFFu << (8u * b);
-        }
-        pp.mask[w] = m;
-    }
+    pp.set_masks(a.key_offset, a.key_bytes);
     for (uint32_t g = blockIdx.x; g < (65536u >> gs); g += gridDim.x) {
         const uint32_t b0 = g << gs;
         const uint64_t gstart = starts[b0];
@@ -660,16 +706,7 @@ __global__ __launch_bounds__(WG, RSX_B16_WAVES(WG)) void rsx_bucket16_medium_ker
         pp.end = end;
         const uint32_t keep = plan->keep + (k >= 4u ? 1u : 0u);
         pp.first = (end > keep && !a.no_skip) ? end - keep : 0;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) {
-            uint32_t mk = 0;
-#pragma unroll
-            for (uint32_t q = 0; q < 4; ++q) {
-                const uint32_t byte = 4u * (uint32_t)w + q;
-                if (byte >= a.key_offset + pp.first && byte < a.key_offset + a.key_bytes) mk |= 0xFFu << (8u * q);
-            }
-            pp.mask[w] = mk;
-        }
+        pp.set_masks(a.key_offset, a.key_bytes);
         for (uint32_t j = 0; j <= kmask; ++j) {
             __syncthreads();
             if (tid == j) {
