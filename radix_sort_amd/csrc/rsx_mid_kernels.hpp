@@ -178,9 +178,6 @@ __global__ __launch_bounds__(512) void rsx_tilescatter_kernel(const MidArgs a) {
 // rsx_wideplan_kernel: one workgroup looks at 16384 elements spread over the array (and the last one), finds the highest
 // bit in which their mapped keys differ from the first element's, and places the window: the 16 bits from there down
 // (its digits may lie across two dwords of the element: elem_digit_any).
-#ifndef RSX_B16_KEEP
-#define RSX_B16_KEEP 4u
-#endif
 template <int ES, bool MAP>
 __global__ __launch_bounds__(1024) void rsx_wideplan_kernel(const Elem<ES>* __restrict__ src, uint64_t n, uint32_t key_offset, uint32_t key_bytes,
                                                             uint32_t key_kind, KeyXform xf, WidePlan* __restrict__ plan) {
@@ -256,7 +253,7 @@ __global__ __launch_bounds__(1024) void rsx_wideplan_kernel(const Elem<ES>* __re
     const uint32_t b_lo = (uint32_t)(top - 15);                // key bits below the window: [0, b_lo)
     const uint32_t pass_end = (b_lo + 7u) / 8u;                // byte digits that hold them
     plan->pass_end = pass_end;
-    plan->keep = (pass_end * 8u - b_lo) != 0u ? RSX_B16_KEEP + 1u : RSX_B16_KEEP;       // (its top digit reaches into the window: constant bits there)
+    plan->keep = (pass_end * 8u - b_lo) != 0u ? 5u : 4u;       // (rsx_bucket16_medium_kernel's parts; its top digit reaches into the window: constant bits there)
     const uint32_t group_end = ((uint32_t)top + 8u) / 8u;      // groups sort by everything up to the window's top
     plan->group_end = group_end;
     plan->group_keep = (group_end * 8u - 1u - (uint32_t)top) != 0u ? 6u : 5u;

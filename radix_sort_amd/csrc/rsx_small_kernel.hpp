@@ -67,6 +67,21 @@ struct PassPlan {
     }
 };
 
+// How many of an array's variable key bits its LDS passes must cover: m keys sorted by b of their bits leave about
+// m^2 / 2^(b+1) pairs of neighbours that agree on them (uniform bits), and mend_listed puts right a few dozen runs in the
+// time of a fraction of a pass: b = 2 ceil(log2 m) - RSX_MEND_SLACK keeps the expected pairs at 2^(RSX_MEND_SLACK - 1) or
+// fewer.  The passes then start at the highest byte digit that leaves them those bits (at least one pass is run).
+#ifndef RSX_MEND_SLACK
+#define RSX_MEND_SLACK 6u
+#endif
+__device__ __forceinline__ uint32_t first_digit_for(const uint32_t m, const uint32_t variable_bits, const uint32_t end) {
+    const uint32_t lg = m <= 1u ? 0u : 32u - (uint32_t)__builtin_clz(m - 1u);
+    const uint32_t need = 2u * lg > RSX_MEND_SLACK ? 2u * lg - RSX_MEND_SLACK : 0u;
+    uint32_t first = variable_bits > need ? (variable_bits - need) >> 3 : 0u;
+    if (first + 1u > end) first = end != 0u ? end - 1u : 0u;
+    return first;
+}
+
 // The per-wave digit counters of these sorts.  (16-bit halves, two to a word, for elements of 12 bytes and more would
 // save 8 KiB of LDS per 1024 threads -- measured: lanes on digits 2k and 2k+1 then meet on one word, and with the extra
 // shifts every size of 16-byte elements ran 8-20 % slower.  Kept as a switch; off.)
@@ -581,7 +596,7 @@ __global__ __launch_bounds__(WG) void rsx_bucket_sort_kernel(const SmallArgs a) 
         // (as in rsx_bucket16_kernel: the passes start at the digit that leaves four, neighbours that still agree are mended)
         PassPlan pp;
         pp.end = a.passes;
-        pp.first = (a.passes > a.keep && !a.no_skip) ? a.passes - a.keep : 0;
+        pp.first = a.no_skip ? 0u : first_digit_for((uint32_t)count, 8u * a.passes, a.passes);
         pp.set_masks(a.key_offset, a.key_bytes);
         uint32_t* s_flag = reinterpret_cast<uint32_t*>(reinterpret_cast<typename WaveCnt<ES>::T*>(smem + (size_t)cape<ES, KPT, WG>() * sizeof(Elem<ES>)) + (WG / WAVE) * RADIX) + (WG / WAVE);
         local_sort_skip<ES, KPT, WG>(a, static_cast<const Elem<ES>*>(a.src) + start, static_cast<Elem<ES>*>(a.data) + start, (uint32_t)count, smem, pp,
@@ -624,8 +639,17 @@ __global__ __launch_bounds__(WG, RSX_B16_WAVES(WG)) void rsx_bucket16_kernel(con
         }
         return;
     }
-    const uint32_t keep = gs == 0 ? plan->keep : plan->group_keep;
-    pp.first = (pp.end > keep && !a.no_skip) ? pp.end - keep : 0;
+    // The passes of an array (a bucket, or a group of 2^gs) run over the byte digits that hold its variable bits -- the
+    // b_lo bits below the window and the gs low bits of the window -- from the digit first_digit_for() names for the
+    // largest array this launch can meet (the largest bucket the scan saw, times the group, at most what LDS holds).
+    const uint32_t b_lo = plan->window_top - 15u;
+    const uint32_t end_sub = pp.end;              // bucket by bucket inside a group that does not fit: every digit, as before
+    if (gs != 0) pp.end = (b_lo + gs + 7u) / 8u;  // (the window's higher bits are the same in the whole group)
+    {
+        const uint64_t big = (uint64_t)plan->scan_max << gs;
+        const uint32_t m = big < (uint64_t)cape<ES, KPT, WG>() ? (uint32_t)big : cape<ES, KPT, WG>();
+        pp.first = a.no_skip ? 0u : first_digit_for(m, b_lo + gs, pp.end);
+    }
     pp.set_masks(a.key_offset, a.key_bytes);
     for (uint32_t g = blockIdx.x; g < (65536u >> gs); g += gridDim.x) {
         const uint32_t b0 = g << gs;
@@ -643,10 +667,16 @@ __global__ __launch_bounds__(WG, RSX_B16_WAVES(WG)) void rsx_bucket16_kernel(con
             if (count != 0) {
                 E* bucket = static_cast<E*>(a.data) + start;
                 if (count <= (uint64_t)cape<ES, KPT, WG>()) {
-                    const uint32_t first = pp.first;
-                    if (!whole) pp.first = 0;
-                    local_sort_skip<ES, KPT, WG>(a, bucket, bucket, (uint32_t)count, smem, pp, s_flag);
-                    if (!whole) pp.first = first;
+                    const uint32_t first = pp.first, end = pp.end;
+                    if (!whole) {
+                        pp.first = 0;
+                        pp.end = end_sub;
+                    }
+                    local_sort_skip<ES, KPT, WG>(a, bucket, bucket, (uint32_t)count, smem, pp, s_flag);  // (a failed mend leaves pp.first = 0)
+                    if (!whole) {
+                        pp.first = first;
+                        pp.end = end;
+                    }
                 } else if (!medium) {  // (never: a bucket above what this workgroup holds makes the verdict VERDICT_MEDIUM, and
                                        // rsx_bucket16_medium_kernel takes it; without this branch the compiler spills 34 registers here)
                     big_bucket_sort<ES, KPT, WG>(a, bucket, static_cast<E*>(scratch) + start, (uint32_t)count, smem);
