@@ -272,8 +272,8 @@ def roofline_of(res, workload, n, d):
         "hbm_gbps_by_design": res["bucket_hbm_gbps"], "hbm_frac_by_design": res["bucket_hbm_gbps"] / HBM_PEAK_GBPS,
         "traffic": pmc_traffic(workload, "bucket16"),
         "note": "frac counts the algorithm's bytes (2*n*s per digit pass, SURVEY 8(d)) for the D-2 passes this launch stands for; "
-                "it can exceed 1 because they run in LDS -- and only the top four of them are run, the neighbours that still "
-                "agree afterwards are mended by the skipped digits -- while the kernel reads and writes the array once "
+                "it can exceed 1 because they run in LDS -- and only as many of the top ones as a bucket of that size needs are "
+                "run (three at 2^30 u64), the neighbours that still agree afterwards are mended by the skipped digits -- while the kernel reads and writes the array once "
                 "(hbm_*_by_design; traffic = rocprofv3 PMC)",
         "per_sort_ms": {"count16 + marginal": res.get("count16_ms_per_sort"), "total16 + scan16": res.get("scan16_ms_per_sort"),
                         "sweeps (2)": 2 * res["sweep_ms_per_launch"], "bucket16": res["bucket_ms_per_launch"]},

@@ -121,9 +121,10 @@ enum {
                                   0: never; 1 (default): arrays of 2 GiB and more, when the count says every bucket
                                   fits; 2: always (any array of 65536+ such elements, buckets that do not fit go through
                                   memory); 3: as 1 without the size floor (above the middle sizes) */
-    RSX_OPT_BUCKET_SKIP = 13,  /* the hybrid's LDS passes: 1 (default) start at the digit that leaves four passes (a 16-bit
-                                  bucket is, as a rule, told apart by its next 32 bits) and put right the neighbours that
-                                  still agree, by the digits skipped; 0: every pass */
+    RSX_OPT_BUCKET_SKIP = 13,  /* the LDS passes of the bucket kernels: 1 (default) start at the digit that leaves them the
+                                  bits an array of that size is, as a rule, told apart by (2 log2 m - 6 of its variable
+                                  bits: three passes for a 16-bit bucket of 2^30 u64 keys) and put right the neighbours
+                                  that still agree, by the digits skipped; 0: every pass */
     RSX_OPT_BUCKET_GROUP = 14  /* the hybrid on arrays whose 16-bit buckets are small (8-byte and wider keys): 1 (default)
                                   a workgroup sorts a group of consecutive buckets as one array; 0: bucket by bucket */
 };

@@ -314,11 +314,10 @@ int launch_mid_split(rsx_ctx* ctx, const void* src, void* dst, size_t n, const r
 }
 
 // ---- ... then the 256 buckets, each sorted by one workgroup --------------------------------------
-// the bucket kernels start their LDS passes at digit passes - 4 (RSX_OPT_BUCKET_SKIP) and compare neighbours on the key
-// bytes from there up
-inline void set_skip_mask(rsx_ctx* ctx, SmallArgs& a, const rsx_layout* L, uint32_t keep = 4) {
+// the bucket kernels start their LDS passes at the digit their bucket's size allows (RSX_OPT_BUCKET_SKIP, first_digit_for)
+// and compare neighbours on the key bytes from there up
+inline void set_skip_mask(rsx_ctx* ctx, SmallArgs& a, const rsx_layout* L) {
     a.no_skip = ctx->bucket_no_skip;
-    a.keep = keep;
     a.key_offset = L->key_offset;  // (the kernel builds its compare masks from these)
     a.key_bytes = L->key_bytes;
 }

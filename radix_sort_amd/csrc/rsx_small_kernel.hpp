@@ -8,7 +8,7 @@
 //  rsx_bucket16_kernel     the last stage of the wide-key hybrid (rsx_mid_kernels.hpp): two sweeps have partitioned
 //                          the array by a 16-bit window of the key; persistent workgroups sort the 65536 buckets (or
 //                          groups of small ones) by the digits below it.
-//  Both bucket kernels start their passes at the digit that leaves four or five (PassPlan) and mend the few
+//  Both bucket kernels start their passes at the digit their arrays' size allows (first_digit_for, PassPlan) and mend the few
 //  neighbours that still agree afterwards by the skipped digits (local_finish, mend_listed).
 //
 // The general path costs a memset, a count kernel and D sweeps whatever the size (>= 10 us each: a sweep of one
@@ -37,8 +37,7 @@ struct SmallArgs {
     // bucket kernel only
     const uint32_t* top_tot;          // the 256 totals of the top digit (rsx_tilescan_kernel)
     uint32_t cap;                     // elements a 1024-thread workgroup sorts in LDS (a 256-thread one: a quarter)
-    uint32_t no_skip;                 // bucket16 kernel: run every pass (1), or start at the digit that leaves four and mend (0)
-    uint32_t keep;                    // ... how many passes that start leaves (4; 5 for groups of buckets)
+    uint32_t no_skip;                 // bucket kernels: run every pass (1), or start at the digit first_digit_for() names and mend (0)
     uint32_t group_shift;             // bucket16 kernel: a workgroup takes 2^group_shift consecutive buckets as ONE array
     uint32_t key_offset, key_bytes;   // bucket kernels: where the key sits in the element (they build their compare masks: PassPlan)
     uint32_t* hint;                   // host-visible report for the host's next forecast: 1 = every bucket of this input fits a
@@ -593,7 +592,7 @@ __global__ __launch_bounds__(WG) void rsx_bucket_sort_kernel(const SmallArgs a) 
     if constexpr (ES < 8) {  // (keys of more than five bytes only: narrower elements never skip)
         local_sort<ES, KPT, WG>(a, static_cast<const Elem<ES>*>(a.src) + start, static_cast<Elem<ES>*>(a.data) + start, (uint32_t)count, smem);
     } else {
-        // (as in rsx_bucket16_kernel: the passes start at the digit that leaves four, neighbours that still agree are mended)
+        // (as in rsx_bucket16_kernel: the passes start at the digit this bucket's size allows, neighbours that still agree are mended)
         PassPlan pp;
         pp.end = a.passes;
         pp.first = a.no_skip ? 0u : first_digit_for((uint32_t)count, 8u * a.passes, a.passes);
@@ -613,9 +612,9 @@ __global__ __launch_bounds__(WG, RSX_B16_WAVES(WG)) void rsx_bucket16_kernel(con
     constexpr int NWAVE = WG / WAVE;
     uint32_t* s_flag = reinterpret_cast<uint32_t*>(reinterpret_cast<typename WaveCnt<ES>::T*>(smem + (size_t)cape<ES, KPT, WG>() * sizeof(E)) + NWAVE * RADIX) + NWAVE;  // (s_misc is [NWAVE]; 16 words there)
     // A bucket of m elements that agree on their window (and everything above it) is, as a rule, told apart by the next
-    // 2 log2(m) bits or so: the passes start at the digit that leaves four -- five if the top one reaches into the
-    // window -- (32+ bits for at most 2^15 elements), the neighbours that still agree afterwards are put right one run
-    // at a time (mend_listed), and a workgroup that meets an input where that does not work -- long runs: few distinct
+    // 2 log2(m) bits or so: the passes start at the digit that leaves them 2 log2(m) - 6 variable bits (first_digit_for:
+    // three passes for the 16384-key buckets of 2^30 u64), the neighbours that still agree afterwards are put right one
+    // run at a time (mend_listed), and a workgroup that meets an input where that does not work -- long runs: few distinct
     // values in those bits -- runs all passes from then on.
     // Small buckets (2^24 u64 keys: 256 each) cost a workgroup ~8 us apiece whatever they hold.  The host then sets
     // group_shift: 2^group_shift consecutive buckets -- a contiguous range of the final order -- are sorted as ONE array,

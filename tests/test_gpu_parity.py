@@ -175,10 +175,12 @@ def test_wide_key_hybrid_counts_from_the_16_bit_counters(rs, torch, orc, t):
 
 @pytest.mark.parametrize("t", ["u64", "i64", "f64", "(u64,u64)", "u128", "(u128,u128)"])
 def test_wide_key_hybrid_mends_the_runs_its_passes_left(rs, torch, orc, t):
-    """The hybrid's LDS passes start at the digit that leaves four; neighbours that still agree afterwards are put right
-    by the skipped digits.  Inputs made for that: (A) many short runs -- elements that share everything but their low 16
-    bits with a neighbour; (B) whole buckets that agree on everything between the top and the low 16 bits (runs too long
-    to mend: the workgroup runs every pass); then uniform keys again.  Payload = index, so stability shows."""
+    """The hybrid's LDS passes start at the digit that leaves them the bits an array of that size needs; neighbours that
+    still agree afterwards are put right by the skipped digits (mend_listed: a list of run heads, one thread per run).
+    Inputs made for that: (A) many short runs -- elements that share everything but their low 16 bits with a neighbour
+    (more heads than the list holds: every pass); (B) whole buckets that agree on everything between the top and the low
+    16 bits (runs too long to mend: the workgroup runs every pass); (C) a few pairs that share everything but their lowest
+    byte (the list, mended); then uniform keys again.  Payload = index, so stability shows."""
     d = _digits(rs, t)
     es, ko, kb, _kind = util.TYPES[t]
     lay = orc.Layout(*util.TYPES[t])
@@ -187,7 +189,7 @@ def test_wide_key_hybrid_mends_the_runs_its_passes_left(rs, torch, orc, t):
     n = _mid_max(es) + 300001
     rng = np.random.default_rng(4242 + es + kb)
     idx = np.arange(n, dtype=np.uint64).view(np.uint8).reshape(n, 8)
-    for case in ("A", "B", "uniform"):
+    for case in ("A", "B", "C", "uniform"):
         raw = np.zeros((n, es), dtype=np.uint8)
         key = rng.integers(0, 256, size=(n, kb), dtype=np.uint8)
         if case == "A":
@@ -197,6 +199,10 @@ def test_wide_key_hybrid_mends_the_runs_its_passes_left(rs, torch, orc, t):
                 key[pick, 2:] = key[pick - 1, 2:]
         elif case == "B":
             key[:, 2:kb - 2] = 0
+        elif case == "C":
+            pick = np.flatnonzero(rng.random(n) < 0.002)
+            pick = pick[pick > 0]
+            key[pick, 1:] = key[pick - 1, 1:]
         raw[:, ko:ko + kb] = key
         for j, b in enumerate(b for b in range(es) if not ko <= b < ko + kb):
             raw[:, b] = idx[:, j] if j < 8 else 0
