@@ -425,7 +425,7 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
             if (D >= 8 && ctx->bucket_group)
                 while (gs < 6 && (avg << (gs + 1)) <= cap512 * 3 / 4) ++gs;
             hipLaunchKernelGGL(rsx_scan16_kernel, dim3(256), dim3(256), 0, st, tot, BT, starts, cap512 / 2, cap512, cap1024, gs >= 2 ? gs : 0u,
-                               ctx->wide_mode == 2 ? 1u : 0u, (uint64_t)wide_cap_for(es) * 150u, (uint64_t)n / 64u, plan, ctx->host_err_dev + 9);
+                               ctx->wide_mode == 2 ? 1u : 0u, (uint64_t)bucket_cape((int)es, medium_kpt_for((int)es), 1024) * 150u, (uint64_t)n / 64u, plan, ctx->host_err_dev + 9);
             RSX_HIP(hipGetLastError());
         }
         rc = begin_control(ctx, st, geom, false);

@@ -222,6 +222,14 @@ constexpr int bucket_kpt_for(int es) { return es <= 4 ? 28 : es == 8 ? 17 : es =
 // wave counters (bucket_cape: 16-byte elements 9020 of 9216 slots); its smaller forms and the middle sizes keep the shorter
 // unrolled loops.
 constexpr int wide_kpt_for(int es) { return es <= 4 ? 28 : es == 8 ? 17 : es == 12 ? 12 : es == 16 ? 9 : es == 24 ? 6 : 5; }
+// ... and of rsx_bucket16_medium_kernel (1024 threads).  It inlines the split, the LDS sort and the sort through memory: with
+// the bucket kernel's 17 eight-byte elements per thread it spilled 113-141 registers into 950-970 bytes of scratch per lane
+// (16 per thread: 792 bytes; 15: 32), and a kernel with that much scratch takes 20-25 us to DISPATCH even when its gate sends
+// it home at once -- every hybrid sort of 8-byte elements paid that (6 % of a 2^23-key sort).
+#ifndef RSX_KMED8
+#define RSX_KMED8 15
+#endif
+constexpr int medium_kpt_for(int es) { return es == 8 ? RSX_KMED8 : wide_kpt_for(es); }
 // whether an array's 1024-thread form is the longer one: when the average bucket is above 7/8 of what the shorter holds
 constexpr bool wide_big_form(int es, uint64_t n) { return n / 65536u > (uint64_t)1024 * (uint64_t)bucket_kpt_for(es) * 7u / 8u; }
 // elements a workgroup of `wg` threads x `kpt` registers holds in LDS (rsx_small_kernel.hpp cape<ES, KPT, WG>, same formula)

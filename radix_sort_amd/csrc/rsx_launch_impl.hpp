@@ -490,8 +490,9 @@ int launch_bucket16(rsx_ctx* ctx, void* data, void* scratch, size_t n, const rsx
         if (big_form) go(integral_constant<int, 1024>{}, integral_constant<int, KBIG>{}, VERDICT_WG1024, 0);
         else go(integral_constant<int, 1024>{}, integral_constant<int, KPT>{}, VERDICT_WG1024, 0);
         {   // the buckets above the chosen form's workgroup (VERDICT_MEDIUM): one workgroup of the largest kind each
-            const size_t lds = (size_t)cape<ES, KBIG, 1024>() * ES + 16 * RADIX * bucket_cnt_bytes(ES) + 64 + 3 * RADIX * sizeof(uint32_t);
-            auto kern = rsx_bucket16_medium_kernel<ES, KBIG, 1024>;
+            constexpr int KMED = medium_kpt_for(ES);
+            const size_t lds = (size_t)cape<ES, KMED, 1024>() * ES + 16 * RADIX * bucket_cnt_bytes(ES) + 64 + 3 * RADIX * sizeof(uint32_t);
+            auto kern = rsx_bucket16_medium_kernel<ES, KMED, 1024>;
             ensure_lds(ctx, reinterpret_cast<const void*>(kern), lds);
             const Gate g{base.word, VERDICT_PATH_MASK | VERDICT_MEDIUM, VERDICT_HYBRID | VERDICT_MEDIUM};
             hipLaunchKernelGGL(kern, dim3((uint32_t)ctx->num_cu), dim3(1024), lds, st, a, starts, scratch, plan, (uint32_t)(256 * KPT), (uint32_t)(512 * KPT),

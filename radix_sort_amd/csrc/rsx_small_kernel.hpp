@@ -717,25 +717,28 @@ __global__ __launch_bounds__(WG, RSX_B16_WAVES(WG)) void rsx_bucket16_medium_ker
         uint32_t k = 0;
         while (k < 8u && (count >> k) > (uint64_t)CAPE * 6u / 10u) ++k;
         if (k > b_lo) k = b_lo;
-        if (k == 0 || (count >> k) > (uint64_t)CAPE || count > 0xFFFFFFFFull) {
-            big_bucket_sort<ES, KPT, WG>(a, bucket, scr, (uint32_t)count, smem);  // (an even number of passes: ends where it began)
-            __syncthreads();
-            continue;
-        }
-        DigitSpec sp{};
-        const uint32_t ebit = 8u * a.key_offset + b_lo - k;
-        sp.word = ebit >> 5;
-        sp.shift = ebit & 31u;
-        const uint32_t kmask = (1u << k) - 1u;
-        uint32_t part_start = 0, part_count = 0;
-        stream_pass<ES, KPT, WG>(a, bucket, scr, (uint32_t)count, smem, [&](const E& x) { return elem_digit_any<ES>(x, sp) & kmask; }, false, part_start,
-                                 part_count);
-        // the parts' passes: as a bucket's, one digit more when the split took half a digit of their distinguishing bits
+        // (ONE call site each for the split, the LDS sort and the sort through memory, and medium_kpt_for() elements per
+        // thread: this kernel's scratch is what every hybrid sort pays for at dispatch, rsx_internal.hpp)
+        const bool split = !(k == 0 || (count >> k) > (uint64_t)CAPE || count > 0xFFFFFFFFull);
+        uint32_t kmask = 0, part_start = 0, part_count = (uint32_t)count;  // not split: ONE part, the bucket itself (thread 0's)
         PassPlan pp;
         pp.end = end;
-        const uint32_t keep = plan->keep + (k >= 4u ? 1u : 0u);
-        pp.first = (end > keep && !a.no_skip) ? end - keep : 0;
-        pp.set_masks(a.key_offset, a.key_bytes);
+        pp.first = 0;
+        if (split) {
+            DigitSpec sp{};
+            const uint32_t ebit = 8u * a.key_offset + b_lo - k;
+            sp.word = ebit >> 5;
+            sp.shift = ebit & 31u;
+            kmask = (1u << k) - 1u;
+            part_start = part_count = 0;
+            const uint32_t km = kmask;
+            stream_pass<ES, KPT, WG>(a, bucket, scr, (uint32_t)count, smem, [&](const E& x) { return elem_digit_any<ES>(x, sp) & km; }, false, part_start,
+                                     part_count);
+            // the parts' passes: as a bucket's, one digit more when the split took half a digit of their distinguishing bits
+            const uint32_t keep = plan->keep + (k >= 4u ? 1u : 0u);
+            pp.first = (end > keep && !a.no_skip) ? end - keep : 0;
+            pp.set_masks(a.key_offset, a.key_bytes);
+        }
         for (uint32_t j = 0; j <= kmask; ++j) {
             __syncthreads();
             if (tid == j) {
@@ -745,14 +748,16 @@ __global__ __launch_bounds__(WG, RSX_B16_WAVES(WG)) void rsx_bucket16_medium_ker
             __syncthreads();
             const uint32_t off = s_part[0], cnt = s_part[1];
             if (cnt == 0) continue;
-            if (cnt <= CAPE) {
+            if (split && cnt <= CAPE) {
                 local_sort_skip<ES, KPT, WG>(a, scr + off, bucket + off, cnt, smem, pp, s_flag);
-            } else {  // still too large (its keys crowd on few values of those bits): back to its place, then pass by pass
-                for (uint32_t i = tid; i < cnt; i += WG) bucket[off + i] = scr[off + i];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                __syncthreads();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                big_bucket_sort<ES, KPT, WG>(a, bucket + off, scr + off, cnt, smem);
+            } else {
+                if (split) {  // a part still too large (its keys crowd on few values of those bits): back to its place first
+                    for (uint32_t i = tid; i < cnt; i += WG) bucket[off + i] = scr[off + i];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    __syncthreads();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                big_bucket_sort<ES, KPT, WG>(a, bucket + off, scr + off, cnt, smem);  // (pass by pass; an even number: ends where it began)
             }
         }
         __syncthreads();  // smem belongs to the next bucket
