@@ -394,7 +394,10 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
             RSX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->ovf16), 65536 * sizeof(uint32_t)));
             RSX_HIP(hipMemsetAsync(ctx->ovf16, 0, 65536 * sizeof(uint32_t), st));
         }
-        if (!ctx->wide_buf) RSX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->wide_buf), WIDE_PLAN_OFFSET + sizeof(WidePlan)));
+        if (!ctx->wide_buf) {
+            RSX_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->wide_buf), WIDE_PLAN_OFFSET + sizeof(WidePlan)));
+            RSX_HIP(hipMemsetAsync(reinterpret_cast<char*>(ctx->wide_buf) + WIDE_PLAN_OFFSET, 0, sizeof(WidePlan), st));  // (plan_or, plan_done)
+        }
         uint64_t* tot = reinterpret_cast<uint64_t*>(ctx->wide_buf);
         uint64_t* BT = tot + 65536;
         uint64_t* starts = BT + 256;

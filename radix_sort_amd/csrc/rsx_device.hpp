@@ -320,6 +320,8 @@ struct WidePlan {
     uint32_t scan_done;
     uint32_t scan_max;    // the largest bucket (saturated)
     unsigned long long scan_big;  // elements in buckets above what the largest workgroup holds
+    uint32_t plan_or[8];  // rsx_wideplan_kernel's workgroups OR their samples' differences here; the last one reads and clears
+    uint32_t plan_done;   // ... how many have (zero between sorts: set once when the buffer is made, cleared by the last workgroup)
 };
 
 // --------------------------------------------------------------- histogram --

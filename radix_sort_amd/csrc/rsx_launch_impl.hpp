@@ -363,7 +363,7 @@ int launch_bucket_sort(rsx_ctx* ctx, const void* src, void* dst, const RegionGeo
 }
 
 // ---- wide keys, large arrays: count of the top 16 bits; the buckets sorted in LDS -------------------
-// the hybrid's plan: which 16 bits of the mapped key the array is partitioned by (rsx_wideplan_kernel, one workgroup)
+// the hybrid's plan: which 16 bits of the mapped key the array is partitioned by (rsx_wideplan_kernel)
 template <int ES>
 int launch_wideplan(rsx_ctx* ctx, const void* src, size_t n, const rsx_layout* L, WidePlan* plan, hipStream_t st) {
     if constexpr (ES < 4) {
@@ -371,10 +371,10 @@ int launch_wideplan(rsx_ctx* ctx, const void* src, size_t n, const rsx_layout* L
     } else {
         LaunchTimer lt(ctx, RSX_PROF_SCAN, st);
         if (L->key_kind != RSX_KEY_UNSIGNED)
-            hipLaunchKernelGGL((rsx_wideplan_kernel<ES, true>), dim3(1), dim3(1024), 0, st, static_cast<const Elem<ES>*>(src), (uint64_t)n, L->key_offset,
+            hipLaunchKernelGGL((rsx_wideplan_kernel<ES, true>), dim3(WIDEPLAN_BLOCKS), dim3(1024), 0, st, static_cast<const Elem<ES>*>(src), (uint64_t)n, L->key_offset,
                                L->key_bytes, L->key_kind, make_xform(L), plan);
         else
-            hipLaunchKernelGGL((rsx_wideplan_kernel<ES, false>), dim3(1), dim3(1024), 0, st, static_cast<const Elem<ES>*>(src), (uint64_t)n, L->key_offset,
+            hipLaunchKernelGGL((rsx_wideplan_kernel<ES, false>), dim3(WIDEPLAN_BLOCKS), dim3(1024), 0, st, static_cast<const Elem<ES>*>(src), (uint64_t)n, L->key_offset,
                                L->key_bytes, L->key_kind, make_xform(L), plan);
         RSX_HIP(hipGetLastError());
         return RSX_OK;

@@ -178,33 +178,28 @@ __global__ __launch_bounds__(512) void rsx_tilescatter_kernel(const MidArgs a) {
 // rsx_wideplan_kernel: one workgroup looks at 16384 elements spread over the array (and the last one), finds the highest
 // bit in which their mapped keys differ from the first element's, and places the window: the 16 bits from there down
 // (its digits may lie across two dwords of the element: elem_digit_any).
+// WIDEPLAN_BLOCKS workgroups of 1024 threads take one sample each (16384 in all: as ONE workgroup, 16 dependent rounds
+// of loads scattered over the whole array, this kernel took 19 us at 2^23 keys and 38 us at 2^30 -- TLB misses of one CU),
+// OR their differences into plan->plan_or, and the last one to finish makes the plan and clears the accumulators.
+constexpr uint32_t WIDEPLAN_BLOCKS = 16;
 template <int ES, bool MAP>
 __global__ __launch_bounds__(1024) void rsx_wideplan_kernel(const Elem<ES>* __restrict__ src, uint64_t n, uint32_t key_offset, uint32_t key_bytes,
                                                             uint32_t key_kind, KeyXform xf, WidePlan* __restrict__ plan) {
     constexpr int NW = ES / 4;
     __shared__ uint32_t s_or[16][NW];
+    __shared__ uint32_t s_last;
     const uint32_t tid = threadIdx.x;
     Elem<ES> first = src[0];
     if constexpr (MAP) key_map<ES, false>(first, xf);
     uint32_t acc[NW];
+    {
+        const uint64_t step = n / 16384u > 0 ? n / 16384u : 1;
+        uint64_t i = ((uint64_t)blockIdx.x * 1024u + tid) * step;
+        if (blockIdx.x == gridDim.x - 1 && tid == 1023) i = n - 1;
+        Elem<ES> e = src[i < n ? i : 0];
+        if constexpr (MAP) key_map<ES, false>(e, xf);
 #pragma unroll
-    for (int w = 0; w < NW; ++w) acc[w] = 0;
-    const uint64_t step = n / 16384u > 0 ? n / 16384u : 1;
-    constexpr int BATCH = ES <= 16 ? 8 : 4;  // loads in flight per thread
-    for (uint32_t k0 = 0; k0 < 16; k0 += BATCH) {
-        Elem<ES> e[BATCH];
-#pragma unroll
-        for (int u = 0; u < BATCH; ++u) {
-            uint64_t i = ((uint64_t)(k0 + u) * 1024u + tid) * step;
-            if (k0 + u == 15 && tid == 1023) i = n - 1;
-            e[u] = src[i < n ? i : 0];
-        }
-#pragma unroll
-        for (int u = 0; u < BATCH; ++u) {
-            if constexpr (MAP) key_map<ES, false>(e[u], xf);
-#pragma unroll
-            for (int w = 0; w < NW; ++w) acc[w] |= e[u].w[w] ^ first.w[w];
-        }
+        for (int w = 0; w < NW; ++w) acc[w] = e.w[w] ^ first.w[w];
     }
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
@@ -214,7 +209,25 @@ __global__ __launch_bounds__(1024) void rsx_wideplan_kernel(const Elem<ES>* __re
         if ((tid & 63u) == 0u) s_or[tid >> 6][w] = v;
     }
     __syncthreads();
-    if (tid != 0) return;
+    if (tid < (uint32_t)NW) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v |= s_or[q][tid];
+        if (v) atomicOr(&plan->plan_or[tid], v);
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&plan->plan_done, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (s_last == 0 || tid != 0) return;
+    __threadfence();
+    uint32_t ors[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        ors[w] = __hip_atomic_load(&plan->plan_or[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&plan->plan_or[w], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (for the next sort)
+    }
+    __hip_atomic_store(&plan->plan_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // highest differing KEY bit (key bit i is element bit 8 * key_offset + i); all indices static: registers, no scratch
     const uint32_t key_lo = 8u * key_offset, key_hi = 8u * (key_offset + key_bytes) - 1u;  // element bits of the key, inclusive
     auto bits_of = [](uint32_t w, uint32_t from, uint32_t to) -> uint32_t {  // bits of dword w whose element bit index is in [from, to]
@@ -226,10 +239,7 @@ __global__ __launch_bounds__(1024) void rsx_wideplan_kernel(const Elem<ES>* __re
     int t = -1;
 #pragma unroll
     for (int w = NW - 1; w >= 0; --w) {
-        uint32_t v = 0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) v |= s_or[q][w];
-        v &= bits_of((uint32_t)w, key_lo, key_hi);
+        const uint32_t v = ors[w] & bits_of((uint32_t)w, key_lo, key_hi);
         if (t < 0 && v != 0u) t = (int)(32u * (uint32_t)w + 31u - (uint32_t)__builtin_clz(v)) - (int)key_lo;
     }
     uint32_t violation = t < 0 ? 1u : 0u;  // every sampled key the same: nothing to place a window by

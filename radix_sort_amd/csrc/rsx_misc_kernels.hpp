@@ -224,7 +224,8 @@ __global__ __launch_bounds__(256) void rsx_scan16_kernel(const uint64_t* __restr
                                                          uint64_t* __restrict__ starts, uint64_t cap256, uint64_t cap512, uint64_t cap1024,
                                                          uint32_t gs_max, uint32_t forced, uint64_t medium_max, uint64_t crowd_max,
                                                          WidePlan* __restrict__ plan, uint32_t* __restrict__ host_verdict) {
-    __shared__ uint64_t ws[4], wb[4];
+    __shared__ uint64_t ws[4], wb[4], s_big[4], s_crowd[4];
+    __shared__ uint32_t s_cnt[4][8];
     __shared__ uint32_t s_last;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, b = blockIdx.x;
     const uint64_t c = tot[(size_t)b * 256u + tid];
@@ -256,17 +257,30 @@ __global__ __launch_bounds__(256) void rsx_scan16_kernel(const uint64_t* __restr
         big = y > big ? y : big;
         crowd += __shfl_xor(crowd, o);
     }
+    // (one set of atomics per WORKGROUP: they all land on one cache line of the plan, which the memory side serialises at
+    // ~12 ns apiece -- per wave, 1024 waves x up to 10 of them, this kernel took 33 us at 2^23 keys and 92 us at 2^30, where
+    // every bucket exceeds the two smaller forms)
     if (lane == 0) {
-        atomicMax(&plan->scan_max, big > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)big);
-        if (crowd) atomicAdd(&plan->scan_big, (unsigned long long)crowd);
-        if (o256) atomicAdd(&plan->scan_cnt[0], o256);
-        if (o512) atomicAdd(&plan->scan_cnt[1], o512);
-        if (o1024) atomicAdd(&plan->scan_cnt[2], o1024);
+        s_cnt[wave][0] = o256;
+        s_cnt[wave][1] = o512;
+        s_cnt[wave][2] = o1024;
 #pragma unroll
-        for (int g = 2; g <= 6; ++g)
-            if (og[g]) atomicAdd(&plan->scan_cnt[1 + g], og[g]);
+        for (int g = 2; g <= 6; ++g) s_cnt[wave][1 + g] = og[g];
+        s_big[wave] = big;
+        s_crowd[wave] = crowd;
     }
     __syncthreads();
+    if (tid < 8) {
+        const uint32_t v = s_cnt[0][tid] + s_cnt[1][tid] + s_cnt[2][tid] + s_cnt[3][tid];
+        if (v) atomicAdd(&plan->scan_cnt[tid], v);
+    } else if (tid == 8) {
+        uint64_t m = s_big[0];
+        for (int w = 1; w < 4; ++w) m = s_big[w] > m ? s_big[w] : m;
+        atomicMax(&plan->scan_max, m > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)m);
+    } else if (tid == 9) {
+        const uint64_t cr = s_crowd[0] + s_crowd[1] + s_crowd[2] + s_crowd[3];
+        if (cr) atomicAdd(&plan->scan_big, (unsigned long long)cr);
+    }
     uint64_t run = wb[0] + wb[1] + wb[2] + wb[3] + x - c;
     for (uint32_t w = 0; w < wave; ++w) run += ws[w];
     starts[(size_t)b * 256u + tid] = run;
