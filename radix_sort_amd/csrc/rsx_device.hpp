@@ -315,11 +315,18 @@ struct WidePlan {
     DigitSpec specs[3];   // [0] low, [1] high digit of the window (plain digits of the MAPPED key); [2] filler (sweeps read pairs)
     uint32_t ref[8];      // the mapped first element
     uint32_t himask[8];   // key bits above the window, per element dword
-    uint32_t scan_cnt[8]; // rsx_scan16_kernel's workgroups add up here: [0..2] buckets above what 256 / 512 / 1024 threads hold,
-                          // [3..7] groups of 2^(g) buckets, g = 2 .. 6, above what 512 hold; [scan_done] how many have (zeroed by the plan kernel)
+    // rsx_scan16_kernel's workgroups add up here, every word on a 128-byte line of its own (atomics on ONE line are
+    // serialised by the memory side at ~12 ns apiece: 256 workgroups x 11 words on one line were most of that kernel's 26 us):
+    // scan_cnt[i * SCAN_LINE]: [0..2] buckets above what 256 / 512 / 1024 threads hold, [3..7] groups of 2^g buckets, g = 2 .. 6,
+    // above what 512 hold; scan_done: how many workgroups have added theirs (all zeroed by the plan kernel)
+    static constexpr uint32_t SCAN_LINE = 32;
+    uint32_t scan_cnt[8 * SCAN_LINE];
     uint32_t scan_done;
+    uint32_t pad_done[SCAN_LINE - 1];
     uint32_t scan_max;    // the largest bucket (saturated)
+    uint32_t pad_max[SCAN_LINE - 1];
     unsigned long long scan_big;  // elements in buckets above what the largest workgroup holds
+    uint32_t pad_big[SCAN_LINE - 2];
     uint32_t plan_or[8];  // rsx_wideplan_kernel's workgroups OR their samples' differences here; the last one reads and clears
     uint32_t plan_done;   // ... how many have (zero between sorts: set once when the buffer is made, cleared by the last workgroup)
 };

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(1024) void rsx_wideplan_kernel(const Elem<ES>* __re
     plan->group_keep = (group_end * 8u - 1u - (uint32_t)top) != 0u ? 6u : 5u;
     plan->window_top = (uint32_t)top;
     plan->violation = violation;
-    for (int i = 0; i < 8; ++i) plan->scan_cnt[i] = 0;
+    for (int i = 0; i < 8; ++i) plan->scan_cnt[i * WidePlan::SCAN_LINE] = 0;
     plan->scan_done = 0;
     plan->scan_max = 0;
     plan->scan_big = 0;

@@ -198,12 +198,14 @@ __global__ __launch_bounds__(256) void rsx_total16_kernel(const uint32_t* __rest
     const uint32_t w = bin >> 1, sh = (bin & 1u) * 16u;
     uint64_t c = ovf[bin];
     if (c) ovf[bin] = 0;
-    for (uint32_t b0 = 0; b0 < parts; b0 += 8) {
-        uint32_t part[8];
+    constexpr uint32_t FLY = 32;  // loads in flight per thread (512 bytes per workgroup and part, 128 KiB apart: with 8 the 256
+                                  // parts of a large array were 32 round trips, 18 us)
+    for (uint32_t b0 = 0; b0 < parts; b0 += FLY) {
+        uint32_t part[FLY];
 #pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) part[k] = b0 + k < parts ? P[(size_t)(b0 + k) * 32768u + w] : 0u;
+        for (uint32_t k = 0; k < FLY; ++k) part[k] = b0 + k < parts ? P[(size_t)(b0 + k) * 32768u + w] : 0u;
 #pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) c += (part[k] >> sh) & 0xFFFFu;
+        for (uint32_t k = 0; k < FLY; ++k) c += (part[k] >> sh) & 0xFFFFu;
     }
     tot[bin] = c;
     uint64_t x = c;
@@ -257,9 +259,9 @@ __global__ __launch_bounds__(256) void rsx_scan16_kernel(const uint64_t* __restr
         big = y > big ? y : big;
         crowd += __shfl_xor(crowd, o);
     }
-    // (one set of atomics per WORKGROUP: they all land on one cache line of the plan, which the memory side serialises at
-    // ~12 ns apiece -- per wave, 1024 waves x up to 10 of them, this kernel took 33 us at 2^23 keys and 92 us at 2^30, where
-    // every bucket exceeds the two smaller forms)
+    // (one set of atomics per WORKGROUP, every word on a line of its own: per wave and on one cache line of the plan -- which
+    // the memory side serialises at ~12 ns apiece: 1024 waves x up to 10 of them -- this kernel took 33 us at 2^23 keys and
+    // 92 us at 2^30, where every bucket exceeds the two smaller forms)
     if (lane == 0) {
         s_cnt[wave][0] = o256;
         s_cnt[wave][1] = o512;
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256) void rsx_scan16_kernel(const uint64_t* __restr
     __syncthreads();
     if (tid < 8) {
         const uint32_t v = s_cnt[0][tid] + s_cnt[1][tid] + s_cnt[2][tid] + s_cnt[3][tid];
-        if (v) atomicAdd(&plan->scan_cnt[tid], v);
+        if (v) atomicAdd(&plan->scan_cnt[tid * WidePlan::SCAN_LINE], v);
     } else if (tid == 8) {
         uint64_t m = s_big[0];
         for (int w = 1; w < 4; ++w) m = s_big[w] > m ? s_big[w] : m;
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(256) void rsx_scan16_kernel(const uint64_t* __restr
     if (s_last == 0 || tid != 0) return;
     __threadfence();
     uint32_t cnt[8];
-    for (int i = 0; i < 8; ++i) cnt[i] = __hip_atomic_load(&plan->scan_cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 0; i < 8; ++i) cnt[i] = __hip_atomic_load(&plan->scan_cnt[i * WidePlan::SCAN_LINE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t n256 = cnt[0], n512 = cnt[1], n1024 = cnt[2];
     // The smallest workgroup that holds all but a handful of the buckets (those few go through memory, one workgroup
     // each: tolerable for buckets of its own size class, not for what exceeds the largest workgroup -- then the LSD
