@@ -418,7 +418,19 @@ __device__ __forceinline__ bool local_check(const PassPlan& pp, const uint32_t n
             ties |= (diff == 0 && i != 0) ? 1u << j : 0u;
         }
     }
-    return __syncthreads_or(ties != 0 ? 1 : 0) != 0;
+    // Neighbours that are the same element -- equal keys without a payload -- are in input order already: an array of few
+    // distinct values (every run longer than a mend would take on) goes straight to memory unless some pair really differs.
+    // (Looked at again by the threads that saw a tie, in a loop of its own: one more value kept through the unrolled loop
+    // above cost the 1024- and 512-thread forms 38 spilled registers.)
+    uint32_t work = 0;
+    for (uint32_t t = ties, j = 0; t != 0; t >>= 1, ++j) {
+        if (!(t & 1u)) continue;
+        const uint32_t i = j * WG + threadIdx.x;
+        const E u = s_elems[i], v = s_elems[i - 1];
+#pragma unroll
+        for (int w = 0; w < ES / 4; ++w) work |= u.w[w] ^ v.w[w];
+    }
+    return __syncthreads_or(work != 0 ? 1 : 0) != 0;
 }
 // (Not inlined: inside the bucket kernels' loop its registers cost the 1024- and 512-thread forms 70-86 spilled ones and
 // 2^30 u64 8 %.  It takes what it needs by value -- no argument block, which would go to scratch.)

@@ -180,7 +180,7 @@ def test_wide_key_hybrid_mends_the_runs_its_passes_left(rs, torch, orc, t):
     Inputs made for that: (A) many short runs -- elements that share everything but their low 16 bits with a neighbour
     (more heads than the list holds: every pass); (B) whole buckets that agree on everything between the top and the low
     16 bits (runs too long to mend: the workgroup runs every pass); (C) a few pairs that share everything but their lowest
-    byte (the list, mended); then uniform keys again.  Payload = index, so stability shows."""
+    byte (the list, mended); (D) 20000 distinct keys (long runs of equal keys: nothing to mend); then uniform keys again.  Payload = index, so stability shows."""
     d = _digits(rs, t)
     es, ko, kb, _kind = util.TYPES[t]
     lay = orc.Layout(*util.TYPES[t])
@@ -189,7 +189,7 @@ def test_wide_key_hybrid_mends_the_runs_its_passes_left(rs, torch, orc, t):
     n = _mid_max(es) + 300001
     rng = np.random.default_rng(4242 + es + kb)
     idx = np.arange(n, dtype=np.uint64).view(np.uint8).reshape(n, 8)
-    for case in ("A", "B", "C", "uniform"):
+    for case in ("A", "B", "C", "D", "uniform"):
         raw = np.zeros((n, es), dtype=np.uint8)
         key = rng.integers(0, 256, size=(n, kb), dtype=np.uint8)
         if case == "A":
@@ -203,6 +203,9 @@ def test_wide_key_hybrid_mends_the_runs_its_passes_left(rs, torch, orc, t):
             pick = np.flatnonzero(rng.random(n) < 0.002)
             pick = pick[pick > 0]
             key[pick, 1:] = key[pick - 1, 1:]
+        elif case == "D":  # few distinct keys, spread out: long runs of EQUAL keys need no mending (and get none)
+            vals = rng.integers(0, 256, size=(20000, kb), dtype=np.uint8)
+            key = vals[rng.integers(0, 20000, size=n)]
         raw[:, ko:ko + kb] = key
         for j, b in enumerate(b for b in range(es) if not ko <= b < ko + kb):
             raw[:, b] = idx[:, j] if j < 8 else 0

@@ -6,6 +6,7 @@ import bench
 types = sys.argv[1:] or ["u64"]
 MODES = [int(v) for v in os.environ.get("MODES", "0,1").split(",")]
 TRI = int(os.environ.get("TRI", "0"))
+DUP = int(os.environ.get("DUP", "0"))
 BITS = int(os.environ.get("BITS", "0")); BASE = int(os.environ.get("BASE", "0"), 0)
 LGS = [int(v) for v in os.environ.get("LGS", "24,26,28,29,30").split(",")]
 gen = {"uniform": rs.GEN_UNIFORM, "zipf": rs.GEN_ZIPF}[os.environ.get("GEN", "uniform")]
@@ -27,6 +28,8 @@ for t in types:
                     ctx.generate_device(tmp.data_ptr(), n, d, gen, 1000 + it, 1.0)
                     a, b = x.view(torch.int64), tmp.view(torch.int64)
                     a.bitwise_right_shift_(2).bitwise_and_((1 << 61) - 1); b.bitwise_right_shift_(2).bitwise_and_((1 << 61) - 1); a.add_(b)
+                if DUP and d.elem_bytes == 8 and d.key_bytes == 8:  # 2^DUP distinct keys, spread out (a multiplicative hash of the top bits)
+                    x.view(torch.int64).bitwise_right_shift_(64 - DUP).bitwise_and_((1 << DUP) - 1).mul_(-7046029254386353131)
                 if BITS and d.elem_bytes == 8 and d.key_bytes == 8:  # keys of a narrow range: base + uniform below 2^BITS
                     x.view(torch.int64).bitwise_and_((1 << BITS) - 1).bitwise_or_(BASE)
                 ctx.verify_device(x.data_ptr(), n, d, out.data_ptr()); torch.cuda.synchronize(); before = out[1].item()
