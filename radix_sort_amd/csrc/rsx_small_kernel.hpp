@@ -418,8 +418,8 @@ __device__ __forceinline__ bool local_check(const PassPlan& pp, const uint32_t n
             ties |= (diff == 0 && i != 0) ? 1u << j : 0u;
         }
     }
-    // Neighbours that are the same element -- equal keys without a payload -- are in input order already: an array of few
-    // distinct values (every run longer than a mend would take on) goes straight to memory unless some pair really differs.
+    // Neighbours that agree on the skipped digits too are equal keys, in input order already: an array of few distinct
+    // keys (every run longer than a mend would take on) goes straight to memory unless some pair really differs.
     // (Looked at again by the threads that saw a tie, in a loop of its own: one more value kept through the unrolled loop
     // above cost the 1024- and 512-thread forms 38 spilled registers.)
     uint32_t work = 0;
@@ -428,7 +428,7 @@ __device__ __forceinline__ bool local_check(const PassPlan& pp, const uint32_t n
         const uint32_t i = j * WG + threadIdx.x;
         const E u = s_elems[i], v = s_elems[i - 1];
 #pragma unroll
-        for (int w = 0; w < ES / 4; ++w) work |= u.w[w] ^ v.w[w];
+        for (int w = 0; w < ES / 4; ++w) work |= (u.w[w] ^ v.w[w]) & pp.low[w];
     }
     return __syncthreads_or(work != 0 ? 1 : 0) != 0;
 }
