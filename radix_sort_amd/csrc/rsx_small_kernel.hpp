@@ -423,9 +423,8 @@ __device__ __forceinline__ bool local_check(const PassPlan& pp, const uint32_t n
     // (Looked at again by the threads that saw a tie, in a loop of its own: one more value kept through the unrolled loop
     // above cost the 1024- and 512-thread forms 38 spilled registers.)
     uint32_t work = 0;
-    for (uint32_t t = ties, j = 0; t != 0; t >>= 1, ++j) {
-        if (!(t & 1u)) continue;
-        const uint32_t i = j * WG + threadIdx.x;
+    for (uint32_t t = ties; t != 0; t &= t - 1u) {  // (one round per tie: a thread of a uniform array has none, or one)
+        const uint32_t i = (uint32_t)__builtin_ctz(t) * WG + threadIdx.x;
         const E u = s_elems[i], v = s_elems[i - 1];
 #pragma unroll
         for (int w = 0; w < ES / 4; ++w) work |= (u.w[w] ^ v.w[w]) & pp.low[w];
