@@ -118,7 +118,8 @@ enum {
                                   top digit not even counted.  2: always split.  3: always LSD passes. */,
     RSX_OPT_WIDE_SORT = 12,    /* large arrays of 8-byte (and wider) keys: count the top 16 bits of the key, two sweeps for
                                   those two digits, then every 16-bit bucket sorted by its remaining digits in LDS.
-                                  0: never; 1 (default): arrays of 2 GiB and more, when the count says every bucket
+                                  0: never; 1 (default): by key width and size (8- and 16-byte keys above the middle sizes, 4-byte keys in
+                                  8-byte elements from 1 GiB, in wider ones from 2 GiB), when the count says every bucket
                                   fits; 2: always (any array of 65536+ such elements, buckets that do not fit go through
                                   memory); 3: as 1 without the size floor (above the middle sizes) */
     RSX_OPT_BUCKET_SKIP = 13,  /* the LDS passes of the bucket kernels: 1 (default) start at the digit that leaves them the

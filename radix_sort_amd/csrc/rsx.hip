@@ -362,9 +362,9 @@ int sort_device_locked(rsx_ctx* ctx, void* d_data, void* d_tmp, size_t n, const 
     // Where it pays (measured, uniform keys, LSD passes / hybrid): keys of 8 and 16 bytes everywhere above the middle
     // sizes -- u64 2^23 x1.34, 2^26 x1.29, 2^28 x1.9; (u64,u64) 2^22 x1.3, 2^26 x1.9; u128 2^22 x2.4, 2^26 x3.8 (small
     // buckets are sorted in groups, rsx_bucket16_kernel) --; 4-byte keys in 8-byte and wider elements (two of four passes
-    // in LDS) x1.2 from 2 GiB on, not below.
+    // in LDS) x1.2 from 2 GiB on; (u32,u32) x1.09 at 1 GiB already (2^27: 1.99 -> 1.83 ms), x0.88 at 2^26.
     const bool wide_type = es >= 8 && D >= 4;
-    const size_t wide_floor = D >= 8 ? 0 : ((size_t)2 << 30);
+    const size_t wide_floor = D >= 8 ? 0 : es == 8 ? ((size_t)1 << 30) : ((size_t)2 << 30);
     const bool wide_size = wide_type && (uint64_t)n > mid_max_for(es);
     bool wide = false;
     if (ctx->wide_mode == 2) {
